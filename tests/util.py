@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import codon_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz"))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    B, H, W = (int(v) for v in z["shape"])
+    variant = str(z["variant"])
+    wkind = str(z["weights"])
+    if wkind == "kat":
+        sd = orc.kat_state(variant)
+    else:
+        sd = orc.he_state(variant, seed={"he": 0, "he1": 1}[wkind])
+    x, y = orc.kat_inputs(B, H, W)
+    return z, variant, sd, x, y
+
+
+def target_for(x):
+    """Same fixed target as tools/make_golden.py::target_for."""
+    B, _, H, W = x.shape
+    i = np.arange(H).reshape(1, 1, H, 1)
+    j = np.arange(W).reshape(1, 1, 1, W)
+    b = np.arange(B).reshape(B, 1, 1, 1)
+    t = 0.5 + 0.45 * np.sin(0.37 * i + 0.11 * b) * np.cos(0.23 * j)
+    return torch.from_numpy(t.astype(np.float32))
+
+
+def rmse(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).pow(2).mean().sqrt())
+
+
+def rel_rmse(a, b):
+    b = torch.as_tensor(b).double()
+    return rmse(a, b) / max(float(b.pow(2).mean().sqrt()), 1e-30)
