@@ -1,0 +1,90 @@
+"""ctypes binding of libcodon_hip.so (C ABI in include/codon_hip.h).
+
+There is NO fallback: if the shared library is missing, was built for another ABI version or a
+call fails, this module raises.  `import torch` happens before the CDLL so that the library's
+NEEDED libamdhip64.so.7 resolves to the HIP runtime torch already loaded (one runtime per
+process: streams and device pointers are shared with torch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+ABI_VERSION = 1
+LIB_NAME = "libcodon_hip.so"
+
+OK = 0
+F32, BF16 = 0, 1
+CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT = 1, 2, 4
+PACK_FWD, PACK_DGRAD = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "height", "width", "cin", "cout", "ksize", "x_ctotal", "x_coff", "y_ctotal", "y_coff",
+        "r_ctotal", "r_coff", "flags", "dtype")]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("ctotal", C.c_int32), ("coff", C.c_int32)]
+
+
+_P, _I, _S = C.c_void_p, C.c_int32, C.c_size_t
+_TP = C.POINTER(Tensor)
+
+# name -> (restype, argtypes); mirrors include/codon_hip.h one to one
+SIGNATURES = {
+    "codon_abi_version": (C.c_int, []),
+    "codon_last_error_string": (C.c_char_p, []),
+    "codon_conv_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
+    "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "codon_cac_stats_tiles": (_I, [_I, _I]),
+    "codon_cac_stats_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _I, _P]),
+    "codon_cac_gate_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_spatial_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
+    "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load():
+    """Load (once) and return the bound library; raise if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"codon_amd: {path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C codon_amd/csrc`. There is no CPU or eager fallback.")
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        v = lib.codon_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"codon_amd: {path} has ABI version {v}, host code expects {ABI_VERSION}")
+        _lib = lib
+        return lib
+
+
+def check(status: int, what: str):
+    if status != OK:
+        msg = load().codon_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"codon_amd: {what} failed with status {status}: {msg}")

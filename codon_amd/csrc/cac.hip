@@ -1,0 +1,268 @@
+// CAC cross-domain gate kernels (HBM-bound).  Reference: /root/reference/CODON_X4/CAC_module.py
+//   CAC_channel.forward :38-63, ChannelPool :78-81, CAC_spatial.forward :90-94,
+//   gate application + block residual CODON_x4.py:85-118.
+// Fcat = cat(out_c, out) (colour channels 0..63, depth channels 64..127) is never built: the two
+// 64-channel producers are read in place.  ONE pass over Fcat yields everything both gates need:
+//   per pixel : max and mean over the 128 channels           (ChannelPool)
+//   per (b,c) : sum and max over H*W, as per-tile partials    (avg_pool2d / max_pool2d, stage 1)
+// The reference reads Fcat four times for the same quantities and memsets a 2.5 GB host tensor
+// per call (CAC_module.py:39); none of that is reproduced.
+
+#include <math.h>
+
+#include "codon_common.h"
+
+namespace codon {
+
+constexpr int STATS_TILE = 2048;  // pixels per workgroup (8 per thread)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// grid = (ntiles, B).  Thread t owns pixels  tile0 + j*1024 + t*4 + {0..3}, j = 0,1  (VEC = 4)
+//                                   or      tile0 + j*256 + t,            j = 0..7  (VEC = 1).
+template <int VEC>
+__global__ __launch_bounds__(256) void cac_stats_kernel(const float* __restrict__ pre_c, long pc_img,
+                                                        const float* __restrict__ pre, long p_img,
+                                                        float* __restrict__ pooled, float* __restrict__ partials,
+                                                        long HW, int ntiles) {
+  constexpr int NJ = 8 / VEC;
+  __shared__ float red[128][4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const long tile0 = (long)tile * STATS_TILE;
+  long pix[NJ];
+  bool ok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    pix[j] = tile0 + (long)j * (256 * VEC) + tid * VEC;
+    ok[j] = pix[j] < HW;  // HW % VEC == 0 for VEC = 4, so a vector is all-in or all-out
+  }
+  float pmax[8], psum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { pmax[i] = -INFINITY; psum[i] = 0.f; }
+
+#pragma unroll 1
+  for (int c = 0; c < 128; ++c) {
+    const float* plane = (c < 64 ? pre_c + b * pc_img + c * HW : pre + b * p_img + (c - 64) * HW);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if constexpr (VEC == 4) {
+        float4 q = ok[j] ? *reinterpret_cast<const float4*>(plane + pix[j]) : make_float4(0, 0, 0, 0);
+        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+      } else {
+        v[j] = ok[j] ? plane[pix[j]] : 0.f;
+      }
+    }
+    float s = 0.f, m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool k = ok[i / VEC];
+      pmax[i] = fmaxf(pmax[i], v[i]);
+      psum[i] += v[i];
+      s += v[i];                       // out-of-range lanes contribute 0
+      m = k ? fmaxf(m, v[i]) : m;
+    }
+    s = wave_sum(s);
+    m = wave_max(m);
+    if (lane == 0) { red[c][wave][0] = s; red[c][wave][1] = m; }
+  }
+  // per-pixel outputs: plane 0 = channel max, plane 1 = channel mean (max FIRST, CAC_module.py:81)
+  float* pm = pooled + (long)b * 2 * HW;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    if (!ok[j]) continue;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(pm + pix[j]) = make_float4(pmax[4 * j], pmax[4 * j + 1], pmax[4 * j + 2], pmax[4 * j + 3]);
+      *reinterpret_cast<float4*>(pm + HW + pix[j]) =
+          make_float4(psum[4 * j] * (1.f / 128.f), psum[4 * j + 1] * (1.f / 128.f), psum[4 * j + 2] * (1.f / 128.f),
+                      psum[4 * j + 3] * (1.f / 128.f));
+    } else {
+      pm[pix[j]] = pmax[j];
+      pm[HW + pix[j]] = psum[j] * (1.f / 128.f);
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const float s = (red[tid][0][0] + red[tid][1][0]) + (red[tid][2][0] + red[tid][3][0]);
+    const float m = fmaxf(fmaxf(red[tid][0][1], red[tid][1][1]), fmaxf(red[tid][2][1], red[tid][3][1]));
+    float2* out = reinterpret_cast<float2*>(partials + (((long)b * ntiles + tile) * 128 + tid) * 2);
+    *out = make_float2(s, m);
+  }
+}
+
+// grid = B, 128 threads.  Second (fixed-order) stage of the global pools + shared MLP + sigmoid.
+__global__ __launch_bounds__(128) void cac_gate_kernel(const float* __restrict__ partials, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ ch,
+                                                       float* __restrict__ pools_out, int ntiles, float inv_hw) {
+  __shared__ float pool[2][128];
+  __shared__ float hid[2][8];
+  const int c = threadIdx.x, b = blockIdx.x;
+  float s = 0.f, m = -INFINITY;
+  const float2* p = reinterpret_cast<const float2*>(partials) + (long)b * ntiles * 128 + c;
+  for (int t = 0; t < ntiles; ++t) {
+    const float2 v = p[(long)t * 128];
+    s += v.x;
+    m = fmaxf(m, v.y);
+  }
+  pool[0][c] = s * inv_hw;
+  pool[1][c] = m;
+  if (pools_out) {
+    pools_out[((long)b * 2 + 0) * 128 + c] = s * inv_hw;
+    pools_out[((long)b * 2 + 1) * 128 + c] = m;
+  }
+  __syncthreads();
+  if (c < 16) {  // hidden layer: Linear(128, 8) + ReLU, for avg (c<8) and max (c>=8)
+    const int which = c >> 3, j = c & 7;
+    float a = b1[j];
+    for (int k = 0; k < 128; ++k) a = fmaf(w1[j * 128 + k], pool[which][k], a);
+    hid[which][j] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (c < 64) {  // Linear(8, 64) for both pools, summed, sigmoid
+    float a0 = b2[c], a1 = b2[c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 = fmaf(w2[c * 8 + j], hid[0][j], a0);
+      a1 = fmaf(w2[c * 8 + j], hid[1][j], a1);
+    }
+    const float z = a0 + a1;
+    ch[(long)b * 64 + c] = 1.f / (1.f + expf(-z));
+  }
+}
+
+// sp = sigmoid(conv5x5_{2->1, pad 2, no bias}(pooled)); one thread per pixel, neighbours via L1/L2.
+__global__ __launch_bounds__(256) void cac_spatial_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
+                                                          float* __restrict__ sp, int H, int W, long total) {
+  __shared__ float wsh[50];
+  if (threadIdx.x < 50) wsh[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= total) return;
+  const int gx = (int)(idx % W);
+  const long t = idx / W;
+  const int gy = (int)(t % H);
+  const int b = (int)(t / H);
+  const long HW = (long)H * W;
+  const float* base = pooled + (long)b * 2 * HW;
+  float a = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+      const int yy = gy + dy - 2;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int xx = gx + dx - 2;
+        if (xx < 0 || xx >= W) continue;
+        a = fmaf(wsh[(c * 5 + dy) * 5 + dx], base[c * HW + (long)yy * W + xx], a);
+      }
+    }
+  }
+  sp[(long)b * HW + (long)gy * W + gx] = 1.f / (1.f + expf(-a));
+}
+
+// out = pre * (ch*sp) + inputs  for both streams (blockIdx.z selects the stream).
+struct ApplyStream {
+  const float* pre; const float* in; float* out;
+  long pre_img, in_img, out_img;  // elements per image (ctotal*HW); base pointers include coff*HW
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void cac_apply_kernel(const ApplyStream sd, const ApplyStream sc,
+                                                        const float* __restrict__ ch, const float* __restrict__ sp,
+                                                        long HW) {
+  const int bc = blockIdx.y;  // b*64 + c
+  const int b = bc >> 6, c = bc & 63;
+  const long pix = (blockIdx.x * 256L + threadIdx.x) * VEC;
+  if (pix >= HW) return;
+  const ApplyStream& s = blockIdx.z ? sc : sd;
+  const float* p = s.pre + b * s.pre_img + c * HW + pix;
+  const float* r = s.in + b * s.in_img + c * HW + pix;
+  float* o = s.out + b * s.out_img + c * HW + pix;
+  const float g = ch[bc];
+  if constexpr (VEC == 4) {
+    const float4 q4 = *reinterpret_cast<const float4*>(sp + (long)b * HW + pix);
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    const float4 q = *reinterpret_cast<const float4*>(r);
+    *reinterpret_cast<float4*>(o) = make_float4(fmaf(v.x, g * q4.x, q.x), fmaf(v.y, g * q4.y, q.y),
+                                                fmaf(v.z, g * q4.z, q.z), fmaf(v.w, g * q4.w, q.w));
+  } else {
+    *o = fmaf(*p, g * sp[(long)b * HW + pix], *r);
+  }
+}
+
+static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) % 16) == 0;
+}
+
+int cac_stats_tiles(int H, int W) { return (int)(((long)H * W + STATS_TILE - 1) / STATS_TILE); }
+
+int cac_stats_fwd_f32(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
+                      float* partials, hipStream_t stream) {
+  const long HW = (long)H * W;
+  const int nt = cac_stats_tiles(H, W);
+  CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
+  const float* pre_c = (const float*)pc->data + pc->coff * HW;
+  const float* pre = (const float*)pd->data + pd->coff * HW;
+  if (HW % 4 == 0 && aligned16(pre_c, pre, pooled))
+    hipLaunchKernelGGL(cac_stats_kernel<4>, dim3(nt, B), dim3(256), 0, stream, pre_c, pc->ctotal * HW, pre,
+                       pd->ctotal * HW, pooled, partials, HW, nt);
+  else
+    hipLaunchKernelGGL(cac_stats_kernel<1>, dim3(nt, B), dim3(256), 0, stream, pre_c, pc->ctotal * HW, pre,
+                       pd->ctotal * HW, pooled, partials, HW, nt);
+  return check_launch("cac_stats_kernel");
+}
+
+int cac_gate_fwd(int B, int H, int W, const float* partials, const float* w1, const float* b1, const float* w2,
+                 const float* b2, float* ch, float* pools_out, hipStream_t stream) {
+  const int nt = cac_stats_tiles(H, W);
+  hipLaunchKernelGGL(cac_gate_kernel, dim3(B), dim3(128), 0, stream, partials, w1, b1, w2, b2, ch, pools_out, nt,
+                     (float)(1.0 / ((double)H * W)));
+  return check_launch("cac_gate_kernel");
+}
+
+int cac_spatial_fwd(int B, int H, int W, const float* pooled, const float* w, float* sp, hipStream_t stream) {
+  const long total = (long)B * H * W;
+  const long blocks = (total + 255) / 256;
+  CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "cac_spatial_fwd: grid too large");
+  hipLaunchKernelGGL(cac_spatial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pooled, w, sp, H, W, total);
+  return check_launch("cac_spatial_kernel");
+}
+
+int cac_apply_fwd_f32(int B, int H, int W, const codon_tensor* pre, const codon_tensor* pre_c, const float* ch,
+                      const float* sp, const codon_tensor* in, const codon_tensor* in_c, const codon_tensor* out,
+                      const codon_tensor* out_c, hipStream_t stream) {
+  const long HW = (long)H * W;
+  CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: batch %d too large", B);
+  auto mk = [&](const codon_tensor* p, const codon_tensor* i, const codon_tensor* o) {
+    ApplyStream s;
+    s.pre = (const float*)p->data + p->coff * HW; s.pre_img = p->ctotal * HW;
+    s.in = (const float*)i->data + i->coff * HW; s.in_img = i->ctotal * HW;
+    s.out = (float*)o->data + o->coff * HW; s.out_img = o->ctotal * HW;
+    return s;
+  };
+  const ApplyStream sd = mk(pre, in, out), sc = mk(pre_c, in_c, out_c);
+  const bool v4 = HW % 4 == 0 && aligned16(sd.pre, sd.in, sd.out, sp) && aligned16(sc.pre, sc.in, sc.out);
+  if (v4) {
+    const unsigned gx = (unsigned)((HW / 4 + 255) / 256);
+    hipLaunchKernelGGL(cac_apply_kernel<4>, dim3(gx, B * 64, 2), dim3(256), 0, stream, sd, sc, ch, sp, HW);
+  } else {
+    const unsigned gx = (unsigned)((HW + 255) / 256);
+    hipLaunchKernelGGL(cac_apply_kernel<1>, dim3(gx, B * 64, 2), dim3(256), 0, stream, sd, sc, ch, sp, HW);
+  }
+  return check_launch("cac_apply_kernel");
+}
+
+}  // namespace codon

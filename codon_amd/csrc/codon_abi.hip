@@ -1,0 +1,157 @@
+// extern "C" surface of libcodon_hip.so (see include/codon_hip.h): argument validation, dtype
+// dispatch, error strings.  Never throws, never allocates device memory, never synchronises.
+
+#include <stdarg.h>
+#include <string.h>
+
+#include "codon_common.h"
+
+namespace codon {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CODON_ERR_LAUNCH;
+  }
+  return CODON_OK;
+}
+
+// kernels (defined in the other translation units)
+int conv_ck(int ks);
+int conv2d_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, hipStream_t);
+int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
+int stem_fwd_f32(int, int, int, const float*, const float*, float*, int, int, hipStream_t);
+int head_fwd_f32(int, int, int, const float*, int, int, const float*, const float*, float*, hipStream_t);
+int cac_stats_tiles(int, int);
+int cac_stats_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, hipStream_t);
+int cac_gate_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
+                 hipStream_t);
+int cac_spatial_fwd(int, int, int, const float*, const float*, float*, hipStream_t);
+int cac_apply_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, const float*, const float*,
+                      const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, hipStream_t);
+
+static bool slice_ok(const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + 64 <= t->ctotal; }
+
+static bool shape_ok(int b, int h, int w) { return b > 0 && h > 0 && w > 0 && (long)h * w < (1L << 31); }
+
+}  // namespace codon
+
+using namespace codon;
+
+extern "C" {
+
+int codon_abi_version(void) { return CODON_ABI_VERSION; }
+
+const char* codon_last_error_string(void) { return g_err; }
+
+size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t dtype) {
+  if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 5)) return 0;
+  return (size_t)cout * cin * ksize * ksize * (dtype == CODON_BF16 ? 2 : 4);
+}
+
+int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, int32_t cin, int32_t ksize,
+                           int32_t mode, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(w_oihw && w_packed, CODON_ERR_BAD_ARG, "conv_pack_weight: null pointer");
+  CODON_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, CODON_ERR_UNSUPPORTED, "conv_pack_weight: ksize %d", ksize);
+  CODON_REQUIRE(mode == CODON_PACK_FWD || mode == CODON_PACK_DGRAD, CODON_ERR_BAD_ARG, "conv_pack_weight: mode %d", mode);
+  const int kin = mode == CODON_PACK_DGRAD ? cout : cin;
+  CODON_REQUIRE(cout > 0 && cin > 0 && kin % conv_ck(ksize) == 0, CODON_ERR_UNSUPPORTED,
+                "conv_pack_weight: cin=%d cout=%d not a multiple of the channel chunk", cin, cout);
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: dtype %d", dtype);
+  return pack_weight_f32(w_oihw, (float*)w_packed, cout, cin, ksize, mode, (hipStream_t)stream);
+}
+
+int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y, const void* residual,
+                     codon_stream_t stream) {
+  CODON_REQUIRE(d && x && w_packed && y, CODON_ERR_BAD_ARG, "conv2d_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_fwd: bad shape %dx%dx%d",
+                d->batch, d->height, d->width);
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal, CODON_ERR_BAD_ARG,
+                "conv2d_fwd: input slice [%d,%d) outside %d channels", d->x_coff, d->x_coff + d->cin, d->x_ctotal);
+  CODON_REQUIRE(d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal, CODON_ERR_BAD_ARG,
+                "conv2d_fwd: output slice [%d,%d) outside %d channels", d->y_coff, d->y_coff + d->cout, d->y_ctotal);
+  if (d->flags & CODON_CONV_ADD_RESIDUAL) {
+    CODON_REQUIRE(residual, CODON_ERR_BAD_ARG, "conv2d_fwd: ADD_RESIDUAL without a residual pointer");
+    CODON_REQUIRE(d->r_coff >= 0 && d->r_coff + d->cout <= d->r_ctotal, CODON_ERR_BAD_ARG,
+                  "conv2d_fwd: residual slice outside its buffer");
+  }
+  CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_fwd: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_fwd: dtype %d", d->dtype);
+  return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
+                        (hipStream_t)stream);
+}
+
+int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_oihw, void* y,
+                   int32_t y_ctotal, int32_t y_coff, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(x && w_oihw && y, CODON_ERR_BAD_ARG, "stem_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stem_fwd: bad shape");
+  CODON_REQUIRE(y_coff >= 0 && y_coff + 64 <= y_ctotal, CODON_ERR_BAD_ARG, "stem_fwd: output slice outside buffer");
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
+  return stem_fwd_f32(batch, height, width, x, w_oihw, (float*)y, y_ctotal, y_coff, (hipStream_t)stream);
+}
+
+int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal, int32_t x_coff,
+                   const float* w_oihw, const float* residual, float* y, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(x && w_oihw && residual && y, CODON_ERR_BAD_ARG, "head_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "head_fwd: bad shape");
+  CODON_REQUIRE(x_coff >= 0 && x_coff + 64 <= x_ctotal, CODON_ERR_BAD_ARG, "head_fwd: input slice outside buffer");
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
+  return head_fwd_f32(batch, height, width, (const float*)x, x_ctotal, x_coff, w_oihw, residual, y,
+                      (hipStream_t)stream);
+}
+
+int32_t codon_cac_stats_tiles(int32_t height, int32_t width) {
+  if (height <= 0 || width <= 0) return 0;
+  return cac_stats_tiles(height, width);
+}
+
+int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre_c,
+                        const codon_tensor* pre, float* pooled, float* partials, int32_t dtype,
+                        codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(pre_c) && slice_ok(pre) && pooled && partials, CODON_ERR_BAD_ARG,
+                "cac_stats_fwd: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_stats_fwd: bad shape");
+  CODON_REQUIRE(((uintptr_t)partials % 8) == 0, CODON_ERR_BAD_ARG, "cac_stats_fwd: partials not 8-byte aligned");
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
+  return cac_stats_fwd_f32(batch, height, width, pre_c, pre, pooled, partials, (hipStream_t)stream);
+}
+
+int codon_cac_gate_fwd(int32_t batch, int32_t height, int32_t width, const float* partials, const float* w1,
+                       const float* b1, const float* w2, const float* b2, float* ch, float* pools_out,
+                       codon_stream_t stream) {
+  CODON_REQUIRE(partials && w1 && b1 && w2 && b2 && ch, CODON_ERR_BAD_ARG, "cac_gate_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_gate_fwd: bad shape");
+  return cac_gate_fwd(batch, height, width, partials, w1, b1, w2, b2, ch, pools_out, (hipStream_t)stream);
+}
+
+int codon_cac_spatial_fwd(int32_t batch, int32_t height, int32_t width, const float* pooled, const float* w_spatial,
+                          float* sp, codon_stream_t stream) {
+  CODON_REQUIRE(pooled && w_spatial && sp, CODON_ERR_BAD_ARG, "cac_spatial_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_spatial_fwd: bad shape");
+  return cac_spatial_fwd(batch, height, width, pooled, w_spatial, sp, (hipStream_t)stream);
+}
+
+int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre,
+                        const codon_tensor* pre_c, const float* ch, const float* sp, const codon_tensor* inputs,
+                        const codon_tensor* inputs_c, const codon_tensor* out, const codon_tensor* out_c,
+                        int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(pre) && slice_ok(pre_c) && ch && sp && slice_ok(inputs) && slice_ok(inputs_c) &&
+                    slice_ok(out) && slice_ok(out_c),
+                CODON_ERR_BAD_ARG, "cac_apply_fwd: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_apply_fwd: bad shape");
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
+  return cac_apply_fwd_f32(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c,
+                           (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Shared host-side helpers for libcodon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "codon_hip.h"
+
+namespace codon {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// Call after a kernel launch; converts a sticky launch error into CODON_ERR_LAUNCH.
+int check_launch(const char* what);
+
+#define CODON_REQUIRE(cond, code, ...)       \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::codon::set_error(__VA_ARGS__);       \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md T1): blocks b and b+8 share an
+// XCD under the observed round-robin dispatch, so give each XCD a contiguous range of tiles
+// and neighbouring tiles (which share halos / weights) hit the same 4 MiB L2.  Speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, k = bid >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace codon

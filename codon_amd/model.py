@@ -1,0 +1,255 @@
+"""CODONNet on MI355X: the reference's nn.Module surface over hand-written HIP kernels.
+
+Mirrors (names, constructor, forward signature, state_dict keys/shapes/order, init rule):
+  /root/reference/CODON_X4/CODON_x4.py:18-132      CODONNet  (x4; CODON_X8/CODON_x8.py identical)
+  /root/reference/CODON_X16/CODON_x16.py:92-202    CODONNet  (x16: no attention_c5 / attention_s5)
+  /root/reference/CODON_X4/CAC_module.py:6-94      BasicConv, Flatten, CAC_channel, ChannelPool, CAC_spatial
+  /root/reference/CODON_X4/attention/ResCBAM.py:26-37  ChannelGate (state only; never executed)
+
+The sub-modules below hold PARAMETERS ONLY.  All arithmetic of forward() runs in
+libcodon_hip.so (see include/codon_hip.h); there is no eager / CPU fallback -- CPU tensors raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .ops import Slice
+
+
+class Conv2dParams(nn.Module):
+    """Parameter holder with nn.Conv2d's attribute names (weight is OIHW, no bias)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, he_init=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size, kernel_size)
+        self.stride, self.padding = (1, 1), (kernel_size // 2, kernel_size // 2)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        if he_init:  # CODON_x4.py:50-53
+            n = kernel_size * kernel_size * out_channels
+            self.weight.data.normal_(0, math.sqrt(2.0 / n))
+        else:        # nn.Conv2d default (the CAC convs are created after the He loop)
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("Conv2dParams holds parameters only; CODONNet.forward runs the HIP kernels")
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, bias=False"
+
+
+class BasicConv(nn.Module):  # CAC_module.py:6-20 (bn=False, relu=False on this path)
+    def __init__(self, in_planes, out_planes, kernel_size):
+        super().__init__()
+        self.out_channels = out_planes
+        self.conv = Conv2dParams(in_planes, out_planes, kernel_size)
+        self.bn = None
+        self.relu = None
+
+
+class Flatten(nn.Module):  # CAC_module.py:22-24 (index 0 of the mlp Sequential; no parameters)
+    def forward(self, x):
+        return x.view(x.size(0), -1)
+
+
+class CAC_channel(nn.Module):  # CAC_module.py:26-36
+    def __init__(self, gate_channels, reduction_ratio=16, pool_types=("avg", "max")):
+        super().__init__()
+        self.gate_channels = gate_channels
+        self.mlp = nn.Sequential(Flatten(), nn.Linear(gate_channels, gate_channels // reduction_ratio), nn.ReLU(),
+                                 nn.Linear(gate_channels // reduction_ratio, gate_channels // 2))
+        self.pool_types = list(pool_types)
+
+
+class ChannelGate(nn.Module):  # attention/ResCBAM.py:26-37 -- state only (attention_c5)
+    def __init__(self, gate_channels, reduction_ratio=16, pool_types=("avg", "max")):
+        super().__init__()
+        self.gate_channels = gate_channels
+        self.mlp = nn.Sequential(Flatten(), nn.Linear(gate_channels, gate_channels // reduction_ratio), nn.ReLU(),
+                                 nn.Linear(gate_channels // reduction_ratio, gate_channels))
+        self.pool_types = list(pool_types)
+
+
+class ChannelPool(nn.Module):  # CAC_module.py:78-81 (no parameters; fused into cac_stats)
+    pass
+
+
+class CAC_spatial(nn.Module):  # CAC_module.py:83-89
+    def __init__(self):
+        super().__init__()
+        self.compress = ChannelPool()
+        self.spatial = BasicConv(2, 1, 5)
+
+
+_MAIN_CONVS = [  # (name, cin, cout, k) in the reference's registration order, CODON_x4.py:24-47
+    ("input", 1, 64, 3), ("conv_input", 64, 64, 3), ("conv1", 64, 64, 3), ("conv2", 64, 64, 5),
+    ("conv3", 128, 128, 5), ("confuse", 128, 64, 1),
+    ("input_c", 1, 64, 3), ("conv_input_c", 64, 64, 3), ("conv4", 64, 64, 5), ("conv5", 64, 64, 3),
+    ("conv6", 128, 128, 5), ("confuse_c", 128, 64, 1),
+    ("conv7", 128, 64, 3), ("conv8", 64, 64, 5), ("conv9", 64, 64, 3), ("conv10", 128, 128, 5),
+    ("confuse_fuse", 128, 64, 1), ("conv11", 64, 64, 3), ("output", 64, 1, 3),
+]
+_MFMA_CONVS = [n for n, ci, co, k in _MAIN_CONVS if ci > 1 and co > 1]
+
+
+class _CODONBase(nn.Module):
+    _HAS_UNUSED_GATE5 = True
+
+    def __init__(self):
+        super().__init__()
+        for name, ci, co, k in _MAIN_CONVS:
+            setattr(self, name, Conv2dParams(ci, co, k, he_init=True))
+        self.relu = nn.ReLU()
+        for i in range(5):
+            setattr(self, f"attention_c{i}", CAC_channel(128))
+        for i in range(5):
+            setattr(self, f"attention_s{i}", CAC_spatial())
+        if self._HAS_UNUSED_GATE5:  # CODON_x4.py:64-65: registered, never called
+            self.attention_c5 = ChannelGate(64)
+            self.attention_s5 = CAC_spatial()
+        self._pack_cache: Dict[str, tuple] = {}
+
+    # -- packed weights -------------------------------------------------------------------
+    def _packed(self, name: str, mode: int = L.PACK_FWD) -> torch.Tensor:
+        w = getattr(self, name).weight
+        key = (name, mode)
+        tag = (w.data_ptr(), w._version, w.device, w.dtype)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        packed = ops.packed_weight(w.detach(), mode, torch.float32)
+        self._pack_cache[key] = (tag, packed)
+        return packed
+
+    def __getstate__(self):  # pickle / deepcopy: drop the device-side cache
+        d = self.__dict__.copy()
+        d["_pack_cache"] = {}
+        return d
+
+    def _replicate_for_data_parallel(self):
+        r = super()._replicate_for_data_parallel()
+        r._pack_cache = {}
+        return r
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, x, y):  # x: HR-sized depth, y: grey guidance  (CODON_x4.py:66)
+        if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"CODONNet expects two (B,1,H,W) tensors, got {tuple(x.shape)} and {tuple(y.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("codon_amd.CODONNet runs on MI355X only: move the module and inputs to 'cuda' "
+                               "(there is no CPU fallback)")
+        if x.dtype != torch.float32 or self.input.weight.dtype != torch.float32:
+            raise NotImplementedError(f"codon_amd.CODONNet: dtype {x.dtype} not supported yet (fp32 only)")
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            from .autograd import codon_apply  # training path (custom backward)
+            return codon_apply(self, x, y)
+        return self._forward_impl(x.contiguous(), y.contiguous(), None)
+
+    def _forward_impl(self, x, y, save: Optional[dict]):
+        """Kernel schedule of CODONNet.forward.  With `save` (a dict) every activation the
+        backward needs is kept in fresh buffers; without it buffers are reused across blocks."""
+        B, _, H, W = x.shape
+        dev = x.device
+        new = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
+        P = self._packed
+        keep = save is not None
+
+        # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
+        in2 = new(128)
+        t64 = new(64)
+        ops.stem(x, self.input.weight, Slice(t64))
+        ops.conv2d(Slice(t64), P("conv_input"), Slice(in2, 0, 64), 3, relu=True)
+        t64c = new(64) if keep else t64
+        ops.stem(y, self.input_c.weight, Slice(t64c))
+        ops.conv2d(Slice(t64c), P("conv_input_c"), Slice(in2, 64, 64), 3, relu=True)
+        inputs, inputs_c = Slice(in2, 0, 64), Slice(in2, 64, 64)
+        if keep:
+            save["stem"], save["stem_c"], save["in2"] = t64, t64c, in2
+
+        nt = ops.cac_stats_tiles(H, W)
+        cur = in2                       # (B,128): [depth | colour] block input
+        oc = None
+        stage = r2 = stage_c = r2_c = pre2 = None
+        for i in range(5):
+            if keep or stage is None:
+                stage, r2, pre2 = new(128), new(128), new(128)
+                stage_c, r2_c = (new(128), new(128)) if keep else (stage, r2)
+                pooled = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+                partials = torch.empty((B, nt, 128, 2), dtype=torch.float32, device=dev)
+                sp = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+            ch = torch.empty((B, 64), dtype=torch.float32, device=dev)
+            pools = torch.empty((B, 2, 128), dtype=torch.float32, device=dev) if keep else None
+            out, out_c = Slice(cur, 0, 64), Slice(cur, 64, 64)
+            pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
+            # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
+            ops.conv2d(out, P("conv1"), Slice(stage, 0, 64), 3, relu=True)
+            ops.conv2d(out, P("conv2"), Slice(stage, 64, 64), 5, relu=True)
+            ops.conv2d(Slice(stage), P("conv3"), Slice(r2), 5, relu=True)          # :81
+            ops.conv2d(Slice(r2), P("confuse"), pre, 1)                            # :84
+            # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
+            ops.conv2d(out_c, P("conv4"), Slice(stage_c, 0, 64), 5, relu=True)
+            ops.conv2d(out_c, P("conv5"), Slice(stage_c, 64, 64), 3, relu=True)
+            ops.conv2d(Slice(stage_c), P("conv6"), Slice(r2_c), 5, relu=True)      # :82
+            ops.conv2d(Slice(r2_c), P("confuse_c"), pre_c, 1)                      # :83
+            # CAC gate on Fcat = [pre_c | pre]                                       :85-91
+            ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
+            ops.cac_stats(pre_c, pre, pooled, partials)
+            ops.cac_gate(B, H, W, partials, ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight, ac.mlp[3].bias,
+                         ch, pools)
+            ops.cac_spatial(pooled, asp.spatial.conv.weight, sp)
+            if keep or oc is None:
+                oc = new(128)           # [out | out_c]: also conv7's cat(out, out_c) input  :119
+            ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
+            if keep:
+                save[f"blk{i}"] = dict(x=cur, stage=stage, r2=r2, stage_c=stage_c, r2_c=r2_c, pre2=pre2,
+                                       pooled=pooled, pools=pools, ch=ch, sp=sp)
+            cur = oc
+
+        # fusion trunk                                                               :119-128
+        fuse = new(64)
+        ops.conv2d(Slice(cur), P("conv7"), Slice(fuse), 3, relu=True)
+        if keep:
+            save["oc"], save["fuse"] = cur, fuse
+        f = fuse
+        if not keep:
+            fA = new(64)
+        for i in range(3):
+            if keep:
+                stage, r2, fA = new(128), new(128), new(64)
+            ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True)    # :123
+            ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True)   # :124
+            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True)         # :126
+            ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))  # :127-128
+            if keep:
+                save[f"trunk{i}"] = dict(x=f, stage=stage, r2=r2)
+            f = fA
+        # tail                                                                       :129-132
+        t = new(64) if keep else t64
+        ops.conv2d(Slice(f), P("conv11"), Slice(t), 3, relu=True)
+        outp = torch.empty_like(x)
+        ops.head(Slice(t), self.output.weight, x, outp)
+        if keep:
+            save["f_last"], save["t11"] = f, t
+        return outp
+
+
+class CODONNet(_CODONBase):
+    """x4 / x8 form: 49 state tensors (CODON_X4/CODON_x4.py:18-65)."""
+    _HAS_UNUSED_GATE5 = True
+
+
+class CODONNet16(_CODONBase):
+    """x16 form: 44 state tensors, no attention_c5/attention_s5 (CODON_X16/CODON_x16.py:92-135)."""
+    _HAS_UNUSED_GATE5 = False
+
+
+def strip_module_prefix(state_dict):
+    """x16 checkpoints are saved from nn.DataParallel (CODON_X16/test.py:52,60): keys carry 'module.'."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}

@@ -1,0 +1,128 @@
+/* codon_hip.h -- C ABI of libcodon_hip.so: the MI355X (gfx950) kernels behind CODONNet.
+ *
+ * The reference (619862306/CODON) is eager PyTorch with no native layer; what it calls for
+ * this path are stock ATen ops from nn.Module.forward.  Each entry point below replaces the
+ * ATen op sequence at the cited reference lines.  All pointers are DEVICE pointers; all work
+ * is enqueued on the caller's stream; nothing allocates, synchronises or throws.  Every
+ * function returns CODON_OK (0) or a negative codon_status; codon_last_error_string() gives
+ * the detail for the calling thread.
+ *
+ * Activation layout: NCHW, contiguous, fp32 (CODON_F32) or bf16 (CODON_BF16).  A tensor
+ * argument may be a channel slice of a wider buffer: (ctotal, coff) describe a buffer of
+ * shape (B, ctotal, H, W) of which channels [coff, coff+C) are read/written -- this is how
+ * the torch.cat calls of the reference (CODON_x4.py:79,80,85,119,125) disappear.
+ */
+#ifndef CODON_HIP_H
+#define CODON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODON_ABI_VERSION 1
+
+typedef void* codon_stream_t; /* hipStream_t */
+
+typedef enum codon_status {
+  CODON_OK = 0,
+  CODON_ERR_BAD_ARG = -1,     /* null pointer, non-positive size, misaligned buffer */
+  CODON_ERR_UNSUPPORTED = -2, /* shape / dtype combination with no kernel */
+  CODON_ERR_LAUNCH = -3       /* HIP reported a launch failure */
+} codon_status;
+
+typedef enum codon_dtype { CODON_F32 = 0, CODON_BF16 = 1 } codon_dtype;
+
+enum {
+  CODON_CONV_RELU = 1,         /* y = max(conv, 0)          (self.relu(self.convN(..)))      */
+  CODON_CONV_ADD_RESIDUAL = 2, /* y = conv + residual       (torch.add(out_fuse, fuse) :128) */
+  CODON_CONV_ACCUM_OUT = 4     /* y += conv                 (backward: grads that fan in)    */
+};
+
+enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1 };
+
+/* One stride-1, "same"-padded, bias-free 2-D convolution (every nn.Conv2d of
+ * CODON_X4/CODON_x4.py:24-47 has stride 1, padding k//2, bias=False). */
+typedef struct codon_conv_desc {
+  int32_t batch, height, width;
+  int32_t cin, cout, ksize;   /* ksize in {1,3,5}; (cin,cout) in {64,128}x{64,128} */
+  int32_t x_ctotal, x_coff;   /* input  buffer (B, x_ctotal, H, W), channels [x_coff, x_coff+cin)  */
+  int32_t y_ctotal, y_coff;   /* output buffer (B, y_ctotal, H, W), channels [y_coff, y_coff+cout) */
+  int32_t r_ctotal, r_coff;   /* residual buffer, used with CODON_CONV_ADD_RESIDUAL                */
+  int32_t flags;              /* CODON_CONV_* */
+  int32_t dtype;              /* codon_dtype of x, y, residual and the packed weights              */
+} codon_conv_desc;
+
+/* A 64-channel activation that may be a channel slice of a wider NCHW buffer:
+ * element (b, c, h, w) lives at data[((b*ctotal + coff + c)*H + h)*W + w]. */
+typedef struct codon_tensor {
+  void* data;
+  int32_t ctotal, coff;
+} codon_tensor;
+
+int codon_abi_version(void);
+const char* codon_last_error_string(void);
+
+/* ---- MFMA implicit-GEMM convolutions (99.9 % of the FLOPs) -------------------------------
+ * replaces: self.relu(self.conv{1..11}(..)), self.conv_input(_c), self.confuse(_c/_fuse)
+ *           /root/reference/CODON_X4/CODON_x4.py:69,72,75-78,81-84,120,123-129 */
+
+/* bytes of the packed (K-major, stage-contiguous) weight image the conv kernels read */
+size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t dtype);
+
+/* w_oihw: (cout, cin, k, k) fp32 contiguous (the nn.Conv2d.weight layout).
+ * mode CODON_PACK_FWD  : pack for y = conv(x, w)
+ * mode CODON_PACK_DGRAD: pack the spatially flipped, in/out-transposed filter so that the SAME
+ *                        forward kernel computes dL/dx = conv(dL/dy, w') (cin/cout swap roles). */
+int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, int32_t cin,
+                           int32_t ksize, int32_t mode, int32_t dtype, codon_stream_t stream);
+
+int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
+                     const void* residual, codon_stream_t stream);
+
+/* ---- stem / head stencils (HBM-bound) ----------------------------------------------------
+ * stem: y[:, y_coff:y_coff+64] = relu(conv3x3_{1->64}(x))        CODON_x4.py:68,71
+ * head: y = conv3x3_{64->1}(x) + residual                         CODON_x4.py:130-131 */
+int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
+                   const float* w_oihw, void* y, int32_t y_ctotal, int32_t y_coff, int32_t dtype,
+                   codon_stream_t stream);
+int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal,
+                   int32_t x_coff, const float* w_oihw, const float* residual, float* y,
+                   int32_t dtype, codon_stream_t stream);
+
+/* ---- CAC gate (HBM-bound) -----------------------------------------------------------------
+ * Fcat = cat(out_c, out) is never materialised: pre_c (colour, channels 0..63 of Fcat) and pre
+ * (depth, channels 64..127) are passed separately (CODON_x4.py:85).
+ *
+ * stats : one pass over Fcat producing
+ *           pooled   (B,2,H,W) fp32 : channel max (plane 0) and channel mean (plane 1)
+ *                                      ChannelPool, CAC_module.py:78-81
+ *           partials (B,ntiles,128,2) fp32 : per-tile per-channel {sum, max}
+ *                                      first stage of avg_pool2d / max_pool2d, CAC_module.py:43,47
+ *         ntiles = codon_cac_stats_tiles(H, W).
+ * gate  : finishes the pools (fixed-order second stage, run-to-run deterministic) and applies the
+ *         shared MLP + sigmoid:  ch (B,64) = sigmoid(mlp(avg) + mlp(max))   CAC_module.py:30-35,58-62
+ *         pools_out (B,2,128) receives {avg,max} when non-null (saved for backward).
+ * spatial: sp (B,1,H,W) = sigmoid(conv5x5_{2->1,pad 2}(pooled))            CAC_module.py:88,92-93
+ * apply : out = pre*ch*sp + inputs ; out_c = pre_c*ch*sp + inputs_c         CODON_x4.py:89-91,117-118 */
+int32_t codon_cac_stats_tiles(int32_t height, int32_t width);
+int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre_c,
+                        const codon_tensor* pre, float* pooled, float* partials, int32_t dtype,
+                        codon_stream_t stream);
+int codon_cac_gate_fwd(int32_t batch, int32_t height, int32_t width, const float* partials,
+                       const float* w1, const float* b1, const float* w2, const float* b2,
+                       float* ch, float* pools_out, codon_stream_t stream);
+int codon_cac_spatial_fwd(int32_t batch, int32_t height, int32_t width, const float* pooled,
+                          const float* w_spatial, float* sp, codon_stream_t stream);
+int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre,
+                        const codon_tensor* pre_c, const float* ch, const float* sp,
+                        const codon_tensor* inputs, const codon_tensor* inputs_c,
+                        const codon_tensor* out, const codon_tensor* out_c, int32_t dtype,
+                        codon_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODON_HIP_H */

@@ -1,0 +1,108 @@
+"""End-to-end parity of codon_amd.CODONNet (HIP path through the C ABI) against
+ (1) the golden fixtures recorded from the imported reference (tests/golden), and
+ (2) the CPU oracle on fresh seeded inputs.
+Tolerance: RMSE <= 1e-4 absolute on the network output (north_star), with the fp32 noise
+floor of the reference itself at 1.2e-5 (He-init, output std ~5)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import codon_oracle as orc
+from tests.util import GOLDEN_CASES, load_case, rel_rmse, rmse
+
+RMSE_TOL = 1e-4
+
+
+def _model(variant, sd):
+    from codon_amd import CODONNet, CODONNet16
+    m = (CODONNet16 if variant == "x16" else CODONNet)()
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_forward_matches_golden(name):
+    z, variant, sd, x, y = load_case(name)
+    m = _model(variant, sd)
+    with torch.no_grad():
+        o = m(x.cuda(), y.cuda())
+    assert o.shape == x.shape and o.dtype == torch.float32 and o.is_cuda
+    e = rmse(o.cpu(), z["out"])
+    assert e <= RMSE_TOL, e
+    assert rmse(o.cpu(), z["out_fp64"]) <= RMSE_TOL
+    # well inside the bar: same order as the reference's own fp32 noise
+    assert rel_rmse(o.cpu(), z["out_fp64"]) <= 2e-5
+
+
+def test_intermediates_match_golden():
+    z, variant, sd, x, y = load_case("kat0_x4_1x13x11_taps")
+    m = _model(variant, sd)
+    save = {}
+    with torch.no_grad():
+        m._forward_impl(x.cuda(), y.cuda(), save)
+    for i in range(5):
+        blk = save[f"blk{i}"]
+        assert rel_rmse(blk["pre2"][:, :64].cpu(), z[f"tap.blk{i}.pre"]) < 1e-5
+        assert rel_rmse(blk["pre2"][:, 64:].cpu(), z[f"tap.blk{i}.pre_c"]) < 1e-5
+        assert rel_rmse(blk["ch"].cpu(), z[f"tap.blk{i}.ch"]) < 1e-5
+        assert rel_rmse(blk["sp"].cpu(), z[f"tap.blk{i}.sp"]) < 1e-5
+    assert rel_rmse(save["oc"][:, :64].cpu(), z["tap.blk4.out"]) < 1e-5
+    assert rel_rmse(save["oc"][:, 64:].cpu(), z["tap.blk4.out_c"]) < 1e-5
+    assert rel_rmse(save["fuse"].cpu(), np.maximum(z["tap.fuse.prerelu"], 0)) < 1e-5
+
+
+@pytest.mark.parametrize("shape,seed", [((2, 40, 72), 0), ((1, 75, 93), 1), ((3, 8, 32), 2), ((1, 128, 128), 3)])
+def test_forward_matches_oracle_random(shape, seed):
+    """Config-1 size (1x128x128) and ragged sizes; He-init weights, uniform [0,1] inputs."""
+    B, H, W = shape
+    sd = orc.he_state("x4", seed=10 + seed)
+    g = np.random.default_rng(seed)
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy((g.integers(0, 256, size=(B, 1, H, W)) / 255.0).astype(np.float32))
+    with torch.no_grad():
+        ref = orc.forward(sd, x, y)
+    m = _model("x4", sd)
+    with torch.no_grad():
+        o = m(x.cuda(), y.cuda())
+    assert rmse(o.cpu(), ref) <= RMSE_TOL
+    assert rel_rmse(o.cpu(), ref) <= 2e-5
+
+
+def test_batch_independence_and_determinism():
+    """Images are independent units (no op mixes samples): a batch equals its images
+    run one by one, bit for bit; and two runs are bit-identical (fixed-order reductions)."""
+    sd = orc.he_state("x4", seed=3)
+    g = np.random.default_rng(5)
+    x = torch.from_numpy(g.uniform(0, 1, size=(3, 1, 24, 40)).astype(np.float32)).cuda()
+    y = torch.from_numpy(g.uniform(0, 1, size=(3, 1, 24, 40)).astype(np.float32)).cuda()
+    m = _model("x4", sd)
+    with torch.no_grad():
+        o1, o2 = m(x, y), m(x, y)
+        singles = torch.cat([m(x[i:i + 1], y[i:i + 1]) for i in range(3)])
+    assert torch.equal(o1, o2)
+    assert torch.equal(o1, singles)
+
+
+def test_full_size_properties():
+    """BASELINE config-2 spatial size (480x640) at batch 2: the oracle is too slow here, so check
+    size-independent properties: (a) zero trunk/head weights => output == input depth exactly
+    (global residual, CODON_x4.py:131); (b) translation of a tile interior: a crop run alone equals
+    the same region of the full run away from the 40-pixel receptive-field border is NOT expected
+    (global pools) -- instead check batch independence at full size."""
+    sd = orc.kat_state("x4")
+    m = _model("x4", sd)
+    g = np.random.default_rng(0)
+    x = torch.from_numpy(g.uniform(0, 1, size=(2, 1, 480, 640)).astype(np.float32)).cuda()
+    y = torch.from_numpy(g.uniform(0, 1, size=(2, 1, 480, 640)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        o = m(x, y)
+        o0 = m(x[:1].contiguous(), y[:1].contiguous())
+    assert torch.isfinite(o).all()
+    assert torch.equal(o[:1], o0)
+    sd0 = dict(sd)
+    sd0["output.weight"] = torch.zeros_like(sd["output.weight"])
+    m0 = _model("x4", sd0)
+    with torch.no_grad():
+        assert torch.equal(m0(x, y), x)

@@ -1,0 +1,160 @@
+"""Per-kernel parity: each HIP entry point (called through the C ABI via codon_amd.ops) against
+the same op stated with torch CPU fp32 (the oracle's building blocks).  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import rel_rmse, rmse
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(size=shape) * scale).astype(np.float32))
+
+
+CONV_CASES = [  # (k, cin, cout)
+    (5, 128, 128), (5, 64, 64), (3, 64, 64), (3, 128, 64), (1, 128, 64), (3, 64, 128), (1, 64, 128),
+]
+SHAPES = [(2, 19, 45), (1, 8, 32), (1, 33, 70), (1, 1, 1), (1, 5, 3), (3, 16, 64)]
+
+
+@pytest.mark.parametrize("k,cin,cout", CONV_CASES)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv2d_vs_torch(k, cin, cout, shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, cin, H, W), 1)
+    w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5)
+    ref = F.conv2d(x, w, None, 1, k // 2)
+    xd, wd = x.to(dev), w.to(dev)
+    wp = ops.packed_weight(wd)
+    y = torch.full((B, cout, H, W), float("nan"), device=dev)
+    ops.conv2d(Slice(xd), wp, Slice(y), k)
+    assert rel_rmse(y.cpu(), ref) < 2e-6
+    # fused ReLU
+    ops.conv2d(Slice(xd), wp, Slice(y), k, relu=True)
+    assert rel_rmse(y.cpu(), F.relu(ref)) < 2e-6
+    # residual add
+    r = _rand((B, cout, H, W), 3)
+    ops.conv2d(Slice(xd), wp, Slice(y), k, residual=Slice(r.to(dev)))
+    assert rel_rmse(y.cpu(), ref + r) < 2e-6
+
+
+def test_conv2d_channel_slices():
+    """Reads channels [64,128) of a 128-ch buffer, writes channels [64,128) of another: the
+    cat-free layout of CODON_x4.py:79-80."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 21, 37
+    xb = _rand((B, 128, H, W), 5)
+    w = _rand((64, 64, 5, 5), 6, 0.05)
+    yb = torch.full((B, 128, H, W), 7.0)
+    ref = F.relu(F.conv2d(xb[:, 64:], w, None, 1, 2))
+    xd, yd = xb.to(dev), yb.to(dev)
+    ops.conv2d(Slice(xd, 64, 64), ops.packed_weight(w.to(dev)), Slice(yd, 64, 64), 5, relu=True)
+    got = yd.cpu()
+    assert torch.equal(got[:, :64], yb[:, :64])  # untouched half
+    assert rel_rmse(got[:, 64:], ref) < 2e-6
+
+
+def test_conv2d_dgrad_pack():
+    """PACK_DGRAD weights turn the forward kernel into dL/dx."""
+    from codon_amd import _lib as L
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    for (k, cin, cout) in [(5, 64, 64), (3, 128, 64), (1, 128, 64), (5, 128, 128)]:
+        B, H, W = 1, 13, 40
+        x = _rand((B, cin, H, W), 1).requires_grad_(True)
+        w = _rand((cout, cin, k, k), 2, 0.05)
+        gy = _rand((B, cout, H, W), 3)
+        F.conv2d(x, w, None, 1, k // 2).backward(gy)
+        wp = ops.packed_weight(w.to(dev), L.PACK_DGRAD)
+        gx = torch.empty((B, cin, H, W), device=dev)
+        ops.conv2d(Slice(gy.to(dev)), wp, Slice(gx), k)
+        assert rel_rmse(gx.cpu(), x.grad) < 2e-6, (k, cin, cout)
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 16, 64), (1, 1, 1), (2, 7, 5)])
+def test_stem_head(shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, 1, H, W), 1)
+    w = _rand((64, 1, 3, 3), 2, 0.3)
+    ref = F.relu(F.conv2d(x, w, None, 1, 1))
+    y = torch.empty((B, 64, H, W), device=dev)
+    ops.stem(x.to(dev), w.to(dev), Slice(y))
+    assert rel_rmse(y.cpu(), ref) < 1e-6
+    f = _rand((B, 64, H, W), 3)
+    wo = _rand((1, 64, 3, 3), 4, 0.1)
+    refo = F.conv2d(f, wo, None, 1, 1) + x
+    o = torch.empty((B, 1, H, W), device=dev)
+    ops.head(Slice(f.to(dev)), wo.to(dev), x.to(dev), o)
+    assert rel_rmse(o.cpu(), refo) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 48, 64), (1, 1, 1), (3, 50, 41), (1, 64, 96)])
+def test_cac_gate_kernels(shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    from oracle import codon_oracle as orc
+    dev = _dev()
+    B, H, W = shape
+    pre2 = _rand((B, 128, H, W), 1)           # [pre | pre_c]
+    in2 = _rand((B, 128, H, W), 2)
+    w1, b1 = _rand((8, 128), 3, 0.1), _rand((8,), 4, 0.1)
+    w2, b2 = _rand((64, 8), 5, 0.3), _rand((64,), 6, 0.1)
+    ws = _rand((1, 2, 5, 5), 7, 0.2)
+    pre, pre_c = pre2[:, :64], pre2[:, 64:]
+    Fcat = torch.cat((pre_c, pre), 1)
+    ch_ref = orc.cac_channel(Fcat, w1, b1, w2, b2)
+    sp_ref = orc.cac_spatial(Fcat, ws)
+    g = ch_ref[:, :, None, None] * sp_ref
+    out_ref, outc_ref = pre * g + in2[:, :64], pre_c * g + in2[:, 64:]
+
+    p2, i2 = pre2.to(dev), in2.to(dev)
+    nt = ops.cac_stats_tiles(H, W)
+    pooled = torch.empty((B, 2, H, W), device=dev)
+    partials = torch.empty((B, nt, 128, 2), device=dev)
+    ops.cac_stats(Slice(p2, 64, 64), Slice(p2, 0, 64), pooled, partials)
+    assert rel_rmse(pooled[:, 0].cpu(), Fcat.max(1)[0]) == 0.0
+    assert rel_rmse(pooled[:, 1].cpu(), Fcat.mean(1)) < 1e-6
+    ch = torch.empty((B, 64), device=dev)
+    pools = torch.empty((B, 2, 128), device=dev)
+    ops.cac_gate(B, H, W, partials, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), ch, pools)
+    assert rel_rmse(pools[:, 0].cpu(), Fcat.mean((2, 3))) < 1e-5 or rmse(pools[:, 0].cpu(), Fcat.mean((2, 3))) < 1e-6
+    assert torch.equal(pools[:, 1].cpu(), Fcat.amax((2, 3)))
+    assert rmse(ch.cpu(), ch_ref) < 1e-6
+    sp = torch.empty((B, 1, H, W), device=dev)
+    ops.cac_spatial(pooled, ws.to(dev), sp)
+    assert rmse(sp.cpu(), sp_ref) < 1e-6
+    oc = torch.empty((B, 128, H, W), device=dev)
+    ops.cac_apply(Slice(p2, 0, 64), Slice(p2, 64, 64), ch, sp, Slice(i2, 0, 64), Slice(i2, 64, 64),
+                  Slice(oc, 0, 64), Slice(oc, 64, 64))
+    assert rel_rmse(oc[:, :64].cpu(), out_ref) < 1e-6
+    assert rel_rmse(oc[:, 64:].cpu(), outc_ref) < 1e-6
+
+
+def test_error_conventions():
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    x = torch.zeros((1, 48, 4, 4), device=dev)
+    y = torch.zeros((1, 64, 4, 4), device=dev)
+    with pytest.raises(RuntimeError, match="no f32 kernel"):
+        ops.conv2d(Slice(x), torch.zeros(48 * 64 * 9, device=dev), Slice(y), 3)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.conv2d(Slice(x.cpu()), torch.zeros(8), Slice(y.cpu()), 3)
