@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- CODON x4 forward on MI355X: HR depth maps/s at batch 32/GPU, 480x640, fp32
+(BASELINE.json configs[1]).  One "step" = one CODONNet forward over one synthetic batch.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Images are independent units (no op mixes samples), so ranks shard the batch with NO data-path
+collective in forward ("scaling": "weak": 32 images per GPU whatever N).  Rank 0 prints ONE JSON
+line.  `roofline` is measured live for the dominant kernel (the 5x5 128->128 fp32 MFMA conv,
+71.7 % of the FLOPs) with HIP events recorded on the launch stream around each of its launches
+inside the timed region.  `cpu_baseline` times the CPU oracle (a port of the reference's
+eager-PyTorch path, validated against the imported reference) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+FLOP_PER_PIXEL_FWD = 14_856_052          # 2 x 7 428 026 MAC
+ALG_ELEMS_PER_PIXEL = 12_706             # activation elements moved per output pixel
+CONV5_128_MAC_PER_PIXEL = 409_600        # 5*5*128*128
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_inputs(B, H, W, scale, seed, dev):
+    """y = uniform 8-bit grey / 255; x = smooth LR depth field brought to HxW by a
+    bicubic x`scale` upsample, clipped to [0,1] (the reference's inputs are pre-upsampled offline,
+    CODON_X4/test.py:70-77,116-123)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    y = torch.randint(0, 256, (B, 1, H, W), generator=g, device=dev).float() / 255.0
+    lr = torch.rand((B, 1, H // scale + 2, W // scale + 2), generator=g, device=dev)
+    lr = torch.nn.functional.avg_pool2d(lr, 3, 1)                    # smooth: (H/s, W/s)
+    from codon_amd.upsample import bicubic_upsample
+    x = bicubic_upsample(lr.contiguous(), scale).clamp_(0.0, 1.0)
+    return x.contiguous(), y.contiguous()
+
+
+def cpu_baseline(H, W):
+    """Oracle forward on the host cores for ONE image of the workload (bounded: ~10-30 s)."""
+    from oracle import codon_oracle as orc
+    n = int(os.environ.get("CODON_CPU_THREADS", "0")) or (os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    sd = orc.he_state("x4", seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((1, 1, H, W), generator=g)
+    y = torch.rand((1, 1, H, W), generator=g)
+    with torch.no_grad():
+        orc.forward(sd, x[:, :, :64, :64].contiguous(), y[:, :, :64, :64].contiguous())  # warm the op caches
+        t0 = time.perf_counter()
+        orc.forward(sd, x, y)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 image (1x1x{H}x{W} pair) of the batch, one oracle forward, {dt:.1f} s",
+            "mpx_per_s": H * W / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--scale", type=int, default=4, choices=[4, 8, 16])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from codon_amd import CODONNet, CODONNet16, ops
+    B, H, W = a.batch, a.height, a.width
+    torch.manual_seed(0)
+    model = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev).eval()   # reference init rule, seed 0
+    x, y = synth_inputs(B, H, W, a.scale, 1234 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = model(x, y)
+        ops.PROFILE = {"key": (5, 128, 128), "events": []}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = model(x, y)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+    assert torch.isfinite(out).all()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        P = B * H * W
+        maps_s = world * B * a.steps / dt
+        ev = prof["events"]
+        kms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        kflop = 2.0 * CONV5_128_MAC_PER_PIXEL * P
+        ach = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        step_s = dt / a.steps
+        res = {
+            "metric": "HR depth maps/sec (fwd)", "value": maps_s, "unit": "maps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CODON x{a.scale} forward, batch {B}/GPU at {H}x{W}, fp32 "
+                                   f"(BASELINE.json configs[1])" if (B, H, W, a.scale) == (32, 480, 640, 4)
+                       else f"CODON x{a.scale} forward, batch {B}/GPU at {H}x{W}, fp32",
+                       "batch_per_gpu": B, "height": H, "width": W,
+                       "parallelism": f"dp{world}: images sharded across ranks, no collective in forward",
+                       "weights": "reference init rule (He-normal convs, default CAC), torch.manual_seed(0)"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<5,128,128> (conv3/conv6/conv10)",
+                         "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches_timed": len(ev), "avg_launch_ms": kms,
+                         "flop_per_launch": kflop},
+            "whole_forward": {"tflops": FLOP_PER_PIXEL_FWD * P / step_s / 1e12,
+                              "frac_f32_mfma_peak": FLOP_PER_PIXEL_FWD * P / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                              "alg_hbm_gbs": ALG_ELEMS_PER_PIXEL * 4 * P / step_s / 1e9,
+                              "frac_hbm_peak": ALG_ELEMS_PER_PIXEL * 4 * P / step_s / 1e9 / PEAK_HBM_GBS,
+                              "mpx_per_s": world * P / step_s / 1e6},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,8 @@ int cac_spatial_fwd(int, int, int, const float*, const float*, float*, hipStream
 int cac_apply_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, const float*, const float*,
                       const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, hipStream_t);
 
+int bicubic_upsample(int, int, int, int, const float*, const float*, float*, hipStream_t);
+
 static bool slice_ok(const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + 64 <= t->ctotal; }
 
 static bool shape_ok(int b, int h, int w) { return b > 0 && h > 0 && w > 0 && (long)h * w < (1L << 31); }
@@ -152,6 +154,14 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
   CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
   return cac_apply_fwd_f32(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c,
                            (hipStream_t)stream);
+}
+
+int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, int32_t scale, const float* lr,
+                           const float* phase_weights, float* out, codon_stream_t stream) {
+  CODON_REQUIRE(lr && phase_weights && out, CODON_ERR_BAD_ARG, "bicubic_upsample: null pointer");
+  CODON_REQUIRE(scale == 4 || scale == 8 || scale == 16, CODON_ERR_UNSUPPORTED, "bicubic_upsample: scale %d", scale);
+  CODON_REQUIRE(shape_ok(batch, lr_height * scale, lr_width * scale), CODON_ERR_BAD_ARG, "bicubic_upsample: bad shape");
+  return bicubic_upsample(batch, lr_height, lr_width, scale, lr, phase_weights, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

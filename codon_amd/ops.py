@@ -42,6 +42,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+# bench.py sets PROFILE = {"key": (ksize, cin, cout), "events": []} to bracket every launch of one conv
+# variant with HIP events recorded on the launch stream (the live roofline measurement).
+PROFILE = None
+
+
 class Slice:
     """Channels [coff, coff+c) of a contiguous (B, ctotal, H, W) buffer."""
     __slots__ = ("buf", "coff", "c")
@@ -90,9 +95,16 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
                    residual.ctotal if residual else 0, residual.coff if residual else 0, flags, _dt(x.buf))
     if residual is not None:
         assert residual.c == y.c and residual.buf.shape[2:] == x.buf.shape[2:]
+    prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
     with torch.cuda.device(dev):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         L.check(lib.codon_conv2d_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed), _ptr(y.buf),
                                      _ptr(residual.buf if residual else None), _stream(dev)), "conv2d_fwd")
+        if prof is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            prof["events"].append((e0, e1))
 
 
 def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):

@@ -122,6 +122,15 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
                         const codon_tensor* out, const codon_tensor* out_c, int32_t dtype,
                         codon_stream_t stream);
 
+/* ---- synthetic-input generator: x4 / x8 / x16 bicubic upsample ---------------------------------
+ * No reference counterpart (the reference's depth inputs are upsampled offline,
+ * CODON_X4/test.py:70-77); defined in codon_amd/csrc/upsample.hip, restated in
+ * oracle/upsample_oracle.py, required to agree bit for bit.  lr: (B,1,h,w) fp32;
+ * phase_weights: (scale,4) fp32 Keys a=-0.75 weights per output phase; out: (B,1,h*scale,w*scale). */
+int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, int32_t scale,
+                           const float* lr, const float* phase_weights, float* out,
+                           codon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
