@@ -13,6 +13,10 @@
 
 #include "codon_common.h"
 
+// HIP's __fmul_rn/__fadd_rn are plain * and + and would be contracted into v_fma under the default
+// -ffp-contract=fast; this file must round every operation separately.
+#pragma clang fp contract(off)
+
 namespace codon {
 
 __device__ __forceinline__ float dot4_rn(float w0, float w1, float w2, float w3, float p0, float p1, float p2,
