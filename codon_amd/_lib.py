@@ -18,7 +18,7 @@ LIB_NAME = "libcodon_hip.so"
 
 OK = 0
 F32, BF16 = 0, 1
-CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT = 1, 2, 4
+CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU = 1, 2, 4, 8
 PACK_FWD, PACK_DGRAD = 0, 1
 
 
@@ -42,12 +42,25 @@ SIGNATURES = {
     "codon_conv_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
     "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "codon_conv_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
+    "codon_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _I, _P]),
     "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_cac_stats_tiles": (_I, [_I, _I]),
     "codon_cac_stats_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _I, _P]),
     "codon_cac_gate_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "codon_cac_spatial_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
+    "codon_stencil_1to64": (C.c_int, [_I, _I, _I, _P, _P, _TP, _I, _TP, _I, _P]),
+    "codon_conv1ch_wgrad_workspace_bytes": (_S, [_I, _I, _I]),
+    "codon_conv1ch_wgrad": (C.c_int, [_I, _I, _I, _TP, _P, _P, _I, _P, _S, _P]),
+    "codon_ew_add_mask": (C.c_int, [_I, _I, _I, _I, _TP, _TP, _TP, _I, _P]),
+    "codon_cac_bwd_tiles": (_I, [_I, _I]),
+    "codon_cac_bwd_spatial_blocks": (_I, [_I, _I, _I]),
+    "codon_cac_bwd_reduce": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_bwd_gate": (C.c_int, [_I, _I, _I] + [_P] * 14 + [_P]),
+    "codon_cac_bwd_spatial": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_bwd_apply": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _TP, _TP, _TP, _TP,
+                                      _I, _P]),
     "codon_bicubic_upsample": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
 }

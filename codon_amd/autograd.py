@@ -1,0 +1,170 @@
+"""Training path: one torch.autograd.Function for the whole CODONNet.
+
+The reference has no explicit backward: a training step is plain autograd through
+CODON_x4.py:66-132.  Here forward keeps every activation the backward needs (codon_amd.model
+._forward_impl(save=...)) and backward is an explicit kernel schedule:
+  * dL/dx of every MFMA conv = the forward conv kernel on PACK_DGRAD weights, with the ReLU mask of the
+    tensor the gradient flows INTO fused in the epilogue (MASK_RELU) and fan-in fused as ACCUM_OUT;
+  * dL/dw = codon_conv2d_wgrad, accumulating across the 5 / 3 loop iterations that share weights
+    (CODON_x4.py:74,122);
+  * CAC gate backward = ops.cac_backward (4 kernels);
+  * stem / head: stencil + 1-channel wgrad.
+Gradients w.r.t. the two input images are not produced (the reference never asks for them).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import Slice
+
+# parameters in a fixed order: the flat gradient buffer of codon_amd.dist uses the same order
+_CONVS = ["input", "conv_input", "conv1", "conv2", "conv3", "confuse", "input_c", "conv_input_c", "conv4", "conv5",
+          "conv6", "confuse_c", "conv7", "conv8", "conv9", "conv10", "confuse_fuse", "conv11", "output"]
+
+
+def used_parameters(model):
+    """The 44 tensors that receive gradients, in state_dict order (attention_*5 are never used)."""
+    ps = [(n + ".weight", getattr(model, n).weight) for n in _CONVS]
+    for i in range(5):
+        ac = getattr(model, f"attention_c{i}")
+        ps += [(f"attention_c{i}.mlp.1.weight", ac.mlp[1].weight), (f"attention_c{i}.mlp.1.bias", ac.mlp[1].bias),
+               (f"attention_c{i}.mlp.3.weight", ac.mlp[3].weight), (f"attention_c{i}.mlp.3.bias", ac.mlp[3].bias)]
+    for i in range(5):
+        ps.append((f"attention_s{i}.spatial.conv.weight", getattr(model, f"attention_s{i}").spatial.conv.weight))
+    return ps
+
+
+class _CodonFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, y, *params):
+        save = {}
+        with torch.no_grad():
+            out = model._forward_impl(x.contiguous(), y.contiguous(), save)
+        ctx.model, ctx.saved, ctx.x, ctx.y = model, save, x, y
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        model, S, x, y = ctx.model, ctx.saved, ctx.x, ctx.y
+        with torch.no_grad():
+            grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous())
+        ctx.saved = None
+        names = [n for n, _ in used_parameters(model)]
+        return (None, None, None) + tuple(grads[n] for n in names)
+
+
+def codon_apply(model, x, y):
+    params = [p for _, p in used_parameters(model)]
+    return _CodonFn.apply(model, x, y, *params)
+
+
+def _backward_impl(model, S, x, y, gy):
+    B, _, H, W = x.shape
+    dev = x.device
+    new = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
+    G = {}
+
+    def Pd(name):
+        return model._packed(name, L.PACK_DGRAD)
+
+    def wgrad(name, xs: Slice, gs: Slice, k: int):
+        key = name + ".weight"
+        if key in G:
+            ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=True)
+        else:
+            G[key] = torch.empty_like(getattr(model, name).weight)
+            ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=False)
+
+    # ---- tail: y_hat = output(t11) + x ; t11 = relu(conv11(f3))                       :129-131
+    t11, f_last = S["t11"], S["f_last"]
+    g_t = new(64)
+    ops.stencil_1to64(gy, model.output.weight, Slice(g_t), flip=True, mask=Slice(t11))
+    G["output.weight"] = torch.empty_like(model.output.weight)
+    ops.conv1ch_wgrad(Slice(t11), gy, G["output.weight"], flip=True)
+    wgrad("conv11", Slice(f_last), Slice(g_t), 3)
+    g_f = new(64)                                   # dL/df_3 (no ReLU on f)
+    ops.conv2d(Slice(g_t), Pd("conv11"), Slice(g_f), 3)
+    del g_t
+
+    # ---- fusion trunk, iterations 2..0                                                  :122-128
+    g_fuse = None                                   # running dL/dfuse (pre-mask)
+    g_r2, g_stage = new(128), new(128)
+    for i in (2, 1, 0):
+        T = S[f"trunk{i}"]
+        xin, stage, r2 = T["x"], T["stage"], T["r2"]
+        # f_{i+1} = confuse_fuse(r2) + fuse
+        if g_fuse is None:
+            g_fuse = g_f.clone()
+        else:
+            ops.ew_add_mask(Slice(g_fuse), Slice(g_f))
+        wgrad("confuse_fuse", Slice(r2), Slice(g_f), 1)
+        ops.conv2d(Slice(g_f), Pd("confuse_fuse"), Slice(g_r2), 1, relu_mask=Slice(r2))
+        wgrad("conv10", Slice(stage), Slice(g_r2), 5)
+        ops.conv2d(Slice(g_r2), Pd("conv10"), Slice(g_stage), 5, relu_mask=Slice(stage))
+        wgrad("conv8", Slice(xin), Slice(g_stage, 0, 64), 5)
+        wgrad("conv9", Slice(xin), Slice(g_stage, 64, 64), 3)
+        g_prev = new(64)
+        ops.conv2d(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_prev), 5)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_prev), 3, accumulate=True)
+        g_f = g_prev
+    # f_0 is fuse itself; fuse = relu(conv7(oc4))                                         :119-120
+    ops.ew_add_mask(Slice(g_fuse), Slice(g_f), mask=Slice(S["fuse"]))
+    del g_f
+    wgrad("conv7", Slice(S["oc"]), Slice(g_fuse), 3)
+    g_oc = new(128)                                 # dL/d[out | out_c] of block 4
+    ops.conv2d(Slice(g_fuse), Pd("conv7"), Slice(g_oc), 3)
+    del g_fuse
+
+    # ---- MC + CAC blocks 4..0                                                           :74-118
+    in2 = S["in2"]
+    g_in2 = new(128)                                # running dL/d[inputs | inputs_c]
+    g_pre2 = new(128)
+    for i in (4, 3, 2, 1, 0):
+        Bk = S[f"blk{i}"]
+        xin, stage, r2, stage_c, r2_c, pre2 = Bk["x"], Bk["stage"], Bk["r2"], Bk["stage_c"], Bk["r2_c"], Bk["pre2"]
+        ac, asp = getattr(model, f"attention_c{i}"), getattr(model, f"attention_s{i}")
+        dw1, db1, dw2, db2, dws = ops.cac_backward(
+            Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
+            Bk["pooled"], Bk["pools"], ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight, asp.spatial.conv.weight,
+            Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
+            accumulate_in=(i != 4))
+        G[f"attention_c{i}.mlp.1.weight"], G[f"attention_c{i}.mlp.1.bias"] = dw1, db1
+        G[f"attention_c{i}.mlp.3.weight"], G[f"attention_c{i}.mlp.3.bias"] = dw2, db2
+        G[f"attention_s{i}.spatial.conv.weight"] = dws
+        # block input gradient: blocks 1..4 read oc_{i-1}; block 0 reads in2 (accumulate there)
+        if i > 0:
+            g_x, acc0 = g_oc, False                 # g_oc is dead after cac_backward: reuse it
+        else:
+            g_x, acc0 = g_in2, True
+        # depth stream: pre = confuse(r2); r2 = relu(conv3(stage)); stage = [relu(conv1(x)) | relu(conv2(x))]
+        wgrad("confuse", Slice(r2), Slice(g_pre2, 0, 64), 1)
+        ops.conv2d(Slice(g_pre2, 0, 64), Pd("confuse"), Slice(g_r2), 1, relu_mask=Slice(r2))
+        wgrad("conv3", Slice(stage), Slice(g_r2), 5)
+        ops.conv2d(Slice(g_r2), Pd("conv3"), Slice(g_stage), 5, relu_mask=Slice(stage))
+        wgrad("conv1", Slice(xin, 0, 64), Slice(g_stage, 0, 64), 3)
+        wgrad("conv2", Slice(xin, 0, 64), Slice(g_stage, 64, 64), 5)
+        ops.conv2d(Slice(g_stage, 0, 64), Pd("conv1"), Slice(g_x, 0, 64), 3, accumulate=acc0)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True)
+        # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
+        wgrad("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), 1)
+        ops.conv2d(Slice(g_pre2, 64, 64), Pd("confuse_c"), Slice(g_r2), 1, relu_mask=Slice(r2_c))
+        wgrad("conv6", Slice(stage_c), Slice(g_r2), 5)
+        ops.conv2d(Slice(g_r2), Pd("conv6"), Slice(g_stage), 5, relu_mask=Slice(stage_c))
+        wgrad("conv4", Slice(xin, 64, 64), Slice(g_stage, 0, 64), 5)
+        wgrad("conv5", Slice(xin, 64, 64), Slice(g_stage, 64, 64), 3)
+        ops.conv2d(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, accumulate=acc0)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv5"), Slice(g_x, 64, 64), 3, accumulate=True)
+    del g_oc, g_pre2, g_r2, g_stage
+
+    # ---- heads: in2 = [relu(conv_input(stem)) | relu(conv_input_c(stem_c))]            :68-72
+    ops.ew_add_mask(Slice(g_in2), None, mask=Slice(in2))
+    g_s = new(64)
+    for nm_in, nm_ci, st, img, off in (("input", "conv_input", S["stem"], x, 0),
+                                       ("input_c", "conv_input_c", S["stem_c"], y, 64)):
+        wgrad(nm_ci, Slice(st), Slice(g_in2, off, 64), 3)
+        ops.conv2d(Slice(g_in2, off, 64), Pd(nm_ci), Slice(g_s), 3, relu_mask=Slice(st))
+        G[nm_in + ".weight"] = torch.empty_like(getattr(model, nm_in).weight)
+        ops.conv1ch_wgrad(Slice(g_s), img, G[nm_in + ".weight"], flip=False)
+    return G

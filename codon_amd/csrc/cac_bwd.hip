@@ -1,0 +1,472 @@
+// Backward of the CAC gate block (what torch.autograd computes for
+// /root/reference/CODON_X4/CODON_x4.py:85-118 + CAC_module.py:38-63,78-94; the reference has no
+// explicit backward).  Forward:
+//   Fcat = [pre_c | pre]                      (colour channels 0..63, depth 64..127)
+//   ch  = sigmoid(mlp(avgpool(Fcat)) + mlp(maxpool(Fcat)))          (B,64)
+//   sp  = sigmoid(conv5x5(cat(chmax(Fcat), chmean(Fcat))))          (B,1,H,W)
+//   out = pre*ch*sp + inputs ; out_c = pre_c*ch*sp + inputs_c
+// Given g_out, g_out_c this file produces g_pre, g_pre_c, the parameter gradients, and adds
+// g_out / g_out_c into the running gradient of inputs / inputs_c.  Four kernels:
+//   A cac_bwd_reduce : one pass over {g_out, g_out_c, pre, pre_c}: per-(b,c) partial sums of dL/dch,
+//                      dL/dz (pre-sigmoid spatial logits) per pixel, first-arg-max pixel candidates
+//                      for both global max-pools
+//   B cac_bwd_gate   : per image: finish the reductions, sigmoid', MLP backward (per-image parameter
+//                      gradient partials), dL/davg, dL/dmax, arg-max pixels
+//   C cac_bwd_spatial: dL/dpooled (transposed 5x5) + per-block partials of the 5x5 weight gradient
+//   D cac_bwd_apply  : one pass producing g_pre / g_pre_c (direct term + avg-pool broadcast + max-pool
+//                      routing + channel-mean broadcast + channel-max routing to the FIRST arg-max
+//                      channel in Fcat order, as torch.max does) and g_inputs (+)= g_out
+// All reductions are two-stage with a fixed order: deterministic, batch-invariant.
+
+#include <limits.h>
+#include <math.h>
+
+#include "codon_common.h"
+
+namespace codon {
+
+constexpr int BWD_TILE = 2048;  // pixels per workgroup, 8 per thread (same tiling as cac_stats)
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ int wmin(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+struct Sl {  // 64-channel slice: base pointer already offset by coff*HW; img = ctotal*HW
+  const float* p;
+  long img;
+};
+struct SlW {
+  float* p;
+  long img;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load8(const float* plane, const long (&pix)[8 / VEC], const bool (&ok)[8 / VEC],
+                                      float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8 / VEC; ++j) {
+    if constexpr (VEC == 4) {
+      const float4 q = ok[j] ? *reinterpret_cast<const float4*>(plane + pix[j]) : make_float4(0, 0, 0, 0);
+      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    } else {
+      v[j] = ok[j] ? plane[pix[j]] : 0.f;
+    }
+  }
+}
+
+// ---- A -------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl g_out, Sl g_outc, Sl pre, Sl pre_c,
+                                                             const float* __restrict__ ch,
+                                                             const float* __restrict__ sp,
+                                                             const float* __restrict__ pools,  // (B,2,128)
+                                                             float* __restrict__ g_z,          // (B,1,H,W)
+                                                             float* __restrict__ part_gch,     // (B,nt,64)
+                                                             int* __restrict__ part_arg,       // (B,nt,128)
+                                                             long HW, int ntiles) {
+  constexpr int NJ = 8 / VEC;
+  __shared__ float red_s[64][4];
+  __shared__ int red_a[128][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  long pix[NJ];
+  bool ok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    pix[j] = (long)tile * BWD_TILE + (long)j * (256 * VEC) + tid * VEC;
+    ok[j] = pix[j] < HW;
+  }
+  float spv[8], gsp[8];
+  load8<VEC>(sp + (long)b * HW, pix, ok, spv);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gsp[i] = 0.f;
+  const float* mx = pools + ((long)b * 2 + 1) * 128;
+
+#pragma unroll 1
+  for (int c = 0; c < 64; ++c) {
+    float go[8], gc[8], p[8], pc[8];
+    load8<VEC>(g_out.p + b * g_out.img + c * HW, pix, ok, go);
+    load8<VEC>(g_outc.p + b * g_outc.img + c * HW, pix, ok, gc);
+    load8<VEC>(pre.p + b * pre.img + c * HW, pix, ok, p);
+    load8<VEC>(pre_c.p + b * pre_c.img + c * HW, pix, ok, pc);
+    const float chc = ch[b * 64 + c];
+    const float mxc = mx[c], mxd = mx[64 + c];  // Fcat order: colour c, depth 64+c
+    float s = 0.f;
+    int ad = INT_MAX, ac = INT_MAX;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool k = ok[i / VEC];
+      const float gg = go[i] * p[i] + gc[i] * pc[i];
+      s = fmaf(gg, spv[i], s);
+      gsp[i] = fmaf(gg, chc, gsp[i]);
+      const int pi = (int)(pix[i / VEC] + (VEC == 4 ? (i & 3) : 0));
+      if (k && p[i] == mxd) ad = min(ad, pi);
+      if (k && pc[i] == mxc) ac = min(ac, pi);
+    }
+    s = wsum(s);
+    ad = wmin(ad);
+    ac = wmin(ac);
+    if (lane == 0) { red_s[c][wave] = s; red_a[c][wave] = ac; red_a[64 + c][wave] = ad; }
+  }
+  // dL/dz = dL/dsp * sp * (1 - sp)
+  float* gz = g_z + (long)b * HW;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    if (!ok[j]) continue;
+    if constexpr (VEC == 4) {
+      float4 o;
+      o.x = gsp[4 * j] * spv[4 * j] * (1.f - spv[4 * j]);
+      o.y = gsp[4 * j + 1] * spv[4 * j + 1] * (1.f - spv[4 * j + 1]);
+      o.z = gsp[4 * j + 2] * spv[4 * j + 2] * (1.f - spv[4 * j + 2]);
+      o.w = gsp[4 * j + 3] * spv[4 * j + 3] * (1.f - spv[4 * j + 3]);
+      *reinterpret_cast<float4*>(gz + pix[j]) = o;
+    } else {
+      gz[pix[j]] = gsp[j] * spv[j] * (1.f - spv[j]);
+    }
+  }
+  __syncthreads();
+  if (tid < 64)
+    part_gch[((long)b * ntiles + tile) * 64 + tid] =
+        (red_s[tid][0] + red_s[tid][1]) + (red_s[tid][2] + red_s[tid][3]);
+  if (tid < 128)
+    part_arg[((long)b * ntiles + tile) * 128 + tid] =
+        min(min(red_a[tid][0], red_a[tid][1]), min(red_a[tid][2], red_a[tid][3]));
+}
+
+// ---- B -------------------------------------------------------------------------------------------
+// grid = B, 128 threads.  param partial layout per image: w1 (8x128) | b1 (8) | w2 (64x8) | b2 (64) = 1608
+constexpr int GATE_NPARAM = 8 * 128 + 8 + 64 * 8 + 64;
+
+__global__ __launch_bounds__(128) void cac_bwd_gate_kernel(const float* __restrict__ part_gch,
+                                                           const int* __restrict__ part_arg,
+                                                           const float* __restrict__ ch,
+                                                           const float* __restrict__ pools,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2,
+                                                           float* __restrict__ g_pools,    // (B,2,128)
+                                                           int* __restrict__ argpix,       // (B,128)
+                                                           float* __restrict__ part_param, // (B,1608)
+                                                           int ntiles) {
+  __shared__ float pool[2][128], gs[64], hid[2][8], ghid[2][8];
+  const int t = threadIdx.x, b = blockIdx.x;
+  pool[0][t] = pools[((long)b * 2 + 0) * 128 + t];
+  pool[1][t] = pools[((long)b * 2 + 1) * 128 + t];
+  int am = INT_MAX;
+  for (int k = 0; k < ntiles; ++k) am = min(am, part_arg[((long)b * ntiles + k) * 128 + t]);
+  argpix[(long)b * 128 + t] = am;
+  if (t < 64) {
+    float s = 0.f;
+    for (int k = 0; k < ntiles; ++k) s += part_gch[((long)b * ntiles + k) * 64 + t];
+    const float c = ch[(long)b * 64 + t];
+    gs[t] = s * c * (1.f - c);
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int which = t >> 3, j = t & 7;
+    float a = b1[j];
+    for (int k = 0; k < 128; ++k) a = fmaf(w1[j * 128 + k], pool[which][k], a);
+    hid[which][j] = fmaxf(a, 0.f);
+    float g = 0.f;
+    for (int o = 0; o < 64; ++o) g = fmaf(w2[o * 8 + j], gs[o], g);
+    ghid[which][j] = a > 0.f ? g : 0.f;
+  }
+  __syncthreads();
+  float* pp = part_param + (long)b * GATE_NPARAM;
+  {  // dL/dpools
+    float ga = 0.f, gm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ga = fmaf(w1[j * 128 + t], ghid[0][j], ga);
+      gm = fmaf(w1[j * 128 + t], ghid[1][j], gm);
+    }
+    g_pools[((long)b * 2 + 0) * 128 + t] = ga;
+    g_pools[((long)b * 2 + 1) * 128 + t] = gm;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pp[j * 128 + t] = ghid[0][j] * pool[0][t] + ghid[1][j] * pool[1][t];  // dW1
+  if (t < 8) pp[1024 + t] = ghid[0][t] + ghid[1][t];                                               // db1
+  if (t < 64) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pp[1032 + t * 8 + j] = gs[t] * (hid[0][j] + hid[1][j]);            // dW2
+    pp[1032 + 512 + t] = 2.f * gs[t];                                                              // db2
+  }
+}
+
+// out[i] (+)= sum_k part[k*stride + i], fixed order
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int n, int nparts, long stride, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nparts; ++k) s += part[(long)k * stride + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// ---- C -------------------------------------------------------------------------------------------
+// g_pooled[c][q] = sum_{dy,dx} w[c][dy][dx] * g_z[q - (dy-2, dx-2)]
+// dW[c][dy][dx]  = sum_q g_z[q] * pooled[c][q + (dy-2, dx-2)]      (per-block partials)
+__global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __restrict__ g_z,
+                                                              const float* __restrict__ pooled,
+                                                              const float* __restrict__ w,
+                                                              float* __restrict__ g_pooled,
+                                                              float* __restrict__ part_w,  // (nblk, 50)
+                                                              int H, int W, long total) {
+  __shared__ float wsh[50];
+  __shared__ float red[50][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 50) wsh[tid] = w[tid];
+  __syncthreads();
+  const long idx = blockIdx.x * 256L + tid;
+  const bool live = idx < total;
+  const long HW = (long)H * W;
+  int gx = 0, gy = 0, b = 0;
+  if (live) {
+    gx = (int)(idx % W);
+    const long t = idx / W;
+    gy = (int)(t % H);
+    b = (int)(t / H);
+  }
+  const float* gz = g_z + (long)b * HW;
+  const float* pl = pooled + (long)b * 2 * HW;
+  const float gq = live ? gz[(long)gy * W + gx] : 0.f;
+  float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      // transposed conv: neighbour at q - (dy-2, dx-2)
+      const int yy = gy - (dy - 2), xx = gx - (dx - 2);
+      if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float g = gz[(long)yy * W + xx];
+        o0 = fmaf(wsh[dy * 5 + dx], g, o0);
+        o1 = fmaf(wsh[25 + dy * 5 + dx], g, o1);
+      }
+      // weight gradient: pooled at q + (dy-2, dx-2)
+      const int y2 = gy + (dy - 2), x2 = gx + (dx - 2);
+      const bool in2 = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+      float p0 = in2 ? gq * pl[(long)y2 * W + x2] : 0.f;
+      float p1 = in2 ? gq * pl[HW + (long)y2 * W + x2] : 0.f;
+      p0 = wsum(p0);
+      p1 = wsum(p1);
+      if (lane == 0) { red[dy * 5 + dx][wave] = p0; red[25 + dy * 5 + dx][wave] = p1; }
+    }
+  }
+  if (live) {
+    g_pooled[(long)b * 2 * HW + (long)gy * W + gx] = o0;
+    g_pooled[(long)b * 2 * HW + HW + (long)gy * W + gx] = o1;
+  }
+  __syncthreads();
+  if (tid < 50) part_w[(long)blockIdx.x * 50 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+// ---- D -------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void cac_bwd_apply_kernel(Sl g_out, Sl g_outc, Sl pre, Sl pre_c,
+                                                            const float* __restrict__ ch,
+                                                            const float* __restrict__ sp,
+                                                            const float* __restrict__ pooled,    // (B,2,H,W): max, mean
+                                                            const float* __restrict__ g_pooled,  // (B,2,H,W)
+                                                            const float* __restrict__ g_pools,   // (B,2,128): avg, max
+                                                            const int* __restrict__ argpix,      // (B,128)
+                                                            SlW g_pre, SlW g_pre_c, SlW g_in, SlW g_in_c,
+                                                            int accumulate_in, long HW, float inv_hw) {
+  constexpr int NJ = 8 / VEC;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  long pix[NJ];
+  bool ok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    pix[j] = (long)tile * BWD_TILE + (long)j * (256 * VEC) + tid * VEC;
+    ok[j] = pix[j] < HW;
+  }
+  float spv[8], pmax[8], gpmax[8], gpmean[8];
+  load8<VEC>(sp + (long)b * HW, pix, ok, spv);
+  load8<VEC>(pooled + (long)b * 2 * HW, pix, ok, pmax);
+  load8<VEC>(g_pooled + (long)b * 2 * HW, pix, ok, gpmax);
+  load8<VEC>(g_pooled + (long)b * 2 * HW + HW, pix, ok, gpmean);
+  bool done[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { done[i] = false; gpmean[i] *= (1.f / 128.f); }
+  const float* gavg = g_pools + ((long)b * 2 + 0) * 128;
+  const float* gmax = g_pools + ((long)b * 2 + 1) * 128;
+  const int* ap = argpix + (long)b * 128;
+
+#pragma unroll 1
+  for (int fc = 0; fc < 128; ++fc) {  // Fcat order: colour first, so ties route like torch.max(dim=1)
+    const bool colour = fc < 64;
+    const int c = fc & 63;
+    const Sl& go_s = colour ? g_outc : g_out;
+    const Sl& pr_s = colour ? pre_c : pre;
+    const SlW& gp_s = colour ? g_pre_c : g_pre;
+    const SlW& gi_s = colour ? g_in_c : g_in;
+    float go[8], p[8], gi[8];
+    load8<VEC>(go_s.p + b * go_s.img + c * HW, pix, ok, go);
+    load8<VEC>(pr_s.p + b * pr_s.img + c * HW, pix, ok, p);
+    if (accumulate_in) load8<VEC>(gi_s.p + b * gi_s.img + c * HW, pix, ok, gi);
+    const float chc = ch[b * 64 + c];
+    const float ga = gavg[fc] * inv_hw, gm = gmax[fc];
+    const int apx = ap[fc];
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pi = (int)(pix[i / VEC] + (VEC == 4 ? (i & 3) : 0));
+      float v = go[i] * (chc * spv[i]) + ga + gpmean[i];
+      if (pi == apx) v += gm;
+      const bool hit = !done[i] && p[i] == pmax[i];
+      if (hit) v += gpmax[i];
+      done[i] = done[i] || hit;
+      o[i] = v;
+      gi[i] = accumulate_in ? gi[i] + go[i] : go[i];
+    }
+    float* gpo = gp_s.p + b * gp_s.img + c * HW;
+    float* gio = gi_s.p + b * gi_s.img + c * HW;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!ok[j]) continue;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(gpo + pix[j]) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+        *reinterpret_cast<float4*>(gio + pix[j]) = make_float4(gi[4 * j], gi[4 * j + 1], gi[4 * j + 2], gi[4 * j + 3]);
+      } else {
+        gpo[pix[j]] = o[j];
+        gio[pix[j]] = gi[j];
+      }
+    }
+  }
+}
+
+// ---- elementwise: dst = [dst +] src, then dst = mask > 0 ? dst : 0 ---------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void ew_add_mask_kernel(float* __restrict__ dst, long d_img,
+                                                          const float* __restrict__ src, long s_img,
+                                                          const float* __restrict__ mask, long m_img, int C,
+                                                          long HW, int accumulate) {
+  const int bc = blockIdx.y;
+  const int b = bc / C, c = bc % C;
+  const long pix = (blockIdx.x * 256L + threadIdx.x) * VEC;
+  if (pix >= HW) return;
+  float* d = dst + b * d_img + c * HW + pix;
+  if constexpr (VEC == 4) {
+    float4 v = accumulate || !src ? *reinterpret_cast<const float4*>(d) : make_float4(0, 0, 0, 0);
+    if (src) {
+      const float4 s = *reinterpret_cast<const float4*>(src + b * s_img + c * HW + pix);
+      v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    }
+    if (mask) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + b * m_img + c * HW + pix);
+      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+      v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(d) = v;
+  } else {
+    float v = accumulate || !src ? *d : 0.f;
+    if (src) v += src[b * s_img + c * HW + pix];
+    if (mask) v = mask[b * m_img + c * HW + pix] > 0.f ? v : 0.f;
+    *d = v;
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+static bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) % 16) == 0;
+}
+static Sl mk(const codon_tensor* t, long HW) { return Sl{(const float*)t->data + t->coff * HW, t->ctotal * HW}; }
+static SlW mkw(const codon_tensor* t, long HW) { return SlW{(float*)t->data + t->coff * HW, t->ctotal * HW}; }
+
+int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }
+int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W + 255) / 256); }
+
+int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
+                   const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
+                   const float* pools, float* g_z, float* part_gch, int* part_arg, hipStream_t stream) {
+  const long HW = (long)H * W;
+  const int nt = cac_bwd_tiles(H, W);
+  const Sl a = mk(g_out, HW), b = mk(g_outc, HW), c = mk(pre, HW), d = mk(pre_c, HW);
+  if (HW % 4 == 0 && al16(a.p, b.p, c.p, d.p) && al16(sp, g_z))
+    hipLaunchKernelGGL(cac_bwd_reduce_kernel<4>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pools, g_z,
+                       part_gch, part_arg, HW, nt);
+  else
+    hipLaunchKernelGGL(cac_bwd_reduce_kernel<1>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pools, g_z,
+                       part_gch, part_arg, HW, nt);
+  return check_launch("cac_bwd_reduce_kernel");
+}
+
+int cac_bwd_gate(int B, int H, int W, const float* part_gch, const int* part_arg, const float* ch,
+                 const float* pools, const float* w1, const float* b1, const float* w2, float* g_pools, int* argpix,
+                 float* part_param, float* dw1, float* db1, float* dw2, float* db2, hipStream_t stream) {
+  const int nt = cac_bwd_tiles(H, W);
+  hipLaunchKernelGGL(cac_bwd_gate_kernel, dim3(B), dim3(128), 0, stream, part_gch, part_arg, ch, pools, w1, b1, w2,
+                     g_pools, argpix, part_param, nt);
+  int st = check_launch("cac_bwd_gate_kernel");
+  if (st != CODON_OK) return st;
+  // the four gradients are contiguous slices of the per-image partial rows; sum over images, fixed order
+  struct { float* out; int off, n; } parts[4] = {{dw1, 0, 1024}, {db1, 1024, 8}, {dw2, 1032, 512}, {db2, 1544, 64}};
+  for (auto& q : parts) {
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((q.n + 255) / 256), dim3(256), 0, stream, part_param + q.off, q.out,
+                       q.n, B, (long)GATE_NPARAM, 0);
+    st = check_launch("partial_sum_kernel");
+    if (st != CODON_OK) return st;
+  }
+  return CODON_OK;
+}
+
+int cac_bwd_spatial(int B, int H, int W, const float* g_z, const float* pooled, const float* w, float* g_pooled,
+                    float* part_w, float* dw, hipStream_t stream) {
+  const long total = (long)B * H * W;
+  const int nblk = cac_bwd_spatial_blocks(B, H, W);
+  hipLaunchKernelGGL(cac_bwd_spatial_kernel, dim3(nblk), dim3(256), 0, stream, g_z, pooled, w, g_pooled, part_w, H, W,
+                     total);
+  int st = check_launch("cac_bwd_spatial_kernel");
+  if (st != CODON_OK) return st;
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nblk, 50L, 0);
+  return check_launch("partial_sum_kernel");
+}
+
+int cac_bwd_apply(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
+                  const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
+                  const float* pooled, const float* g_pooled, const float* g_pools, const int* argpix,
+                  const codon_tensor* g_pre, const codon_tensor* g_pre_c, const codon_tensor* g_in,
+                  const codon_tensor* g_in_c, int accumulate_in, hipStream_t stream) {
+  const long HW = (long)H * W;
+  const int nt = cac_bwd_tiles(H, W);
+  const Sl a = mk(g_out, HW), b = mk(g_outc, HW), c = mk(pre, HW), d = mk(pre_c, HW);
+  const SlW e = mkw(g_pre, HW), f = mkw(g_pre_c, HW), g = mkw(g_in, HW), h = mkw(g_in_c, HW);
+  const float inv = (float)(1.0 / (double)HW);
+  if (HW % 4 == 0 && al16(a.p, b.p, c.p, d.p) && al16(e.p, f.p, g.p, h.p) && al16(sp, pooled, g_pooled))
+    hipLaunchKernelGGL(cac_bwd_apply_kernel<4>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pooled,
+                       g_pooled, g_pools, argpix, e, f, g, h, accumulate_in, HW, inv);
+  else
+    hipLaunchKernelGGL(cac_bwd_apply_kernel<1>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pooled,
+                       g_pooled, g_pools, argpix, e, f, g, h, accumulate_in, HW, inv);
+  return check_launch("cac_bwd_apply_kernel");
+}
+
+int ew_add_mask(int B, int H, int W, int C, const codon_tensor* dst, const codon_tensor* src,
+                const codon_tensor* mask, int accumulate, hipStream_t stream) {
+  const long HW = (long)H * W;
+  float* d = (float*)dst->data + dst->coff * HW;
+  const float* s = src ? (const float*)src->data + src->coff * HW : nullptr;
+  const float* m = mask ? (const float*)mask->data + mask->coff * HW : nullptr;
+  const long s_img = src ? src->ctotal * HW : 0, m_img = mask ? mask->ctotal * HW : 0;
+  CODON_REQUIRE((long)B * C <= 65535, CODON_ERR_UNSUPPORTED, "ew_add_mask: batch*channels too large");
+  if (HW % 4 == 0 && al16(d, s, m)) {
+    const unsigned gx = (unsigned)((HW / 4 + 255) / 256);
+    hipLaunchKernelGGL(ew_add_mask_kernel<4>, dim3(gx, B * C), dim3(256), 0, stream, d, dst->ctotal * HW, s, s_img, m,
+                       m_img, C, HW, accumulate);
+  } else {
+    const unsigned gx = (unsigned)((HW + 255) / 256);
+    hipLaunchKernelGGL(ew_add_mask_kernel<1>, dim3(gx, B * C), dim3(256), 0, stream, d, dst->ctotal * HW, s, s_img, m,
+                       m_img, C, HW, accumulate);
+  }
+  return check_launch("ew_add_mask_kernel");
+}
+
+}  // namespace codon

@@ -29,8 +29,23 @@ int check_launch(const char* what) {
 // kernels (defined in the other translation units)
 int conv_ck(int ks);
 int conv2d_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, hipStream_t);
+size_t conv_wgrad_workspace_bytes(const codon_conv_desc*);
+int conv2d_wgrad_f32(const codon_conv_desc*, const float*, const float*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
-int stem_fwd_f32(int, int, int, const float*, const float*, float*, int, int, hipStream_t);
+int stem_fwd_f32(int, int, int, const float*, const float*, float*, int, int, int, const float*, int, int, hipStream_t);
+size_t conv1ch_wgrad_workspace_bytes(int, int, int);
+int conv1ch_wgrad(int, int, int, const float*, int, int, const float*, float*, int, float*, size_t, hipStream_t);
+int cac_bwd_tiles(int, int);
+int cac_bwd_spatial_blocks(int, int, int);
+int cac_bwd_reduce(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
+                   const float*, const float*, const float*, float*, float*, int*, hipStream_t);
+int cac_bwd_gate(int, int, int, const float*, const int*, const float*, const float*, const float*, const float*,
+                 const float*, float*, int*, float*, float*, float*, float*, float*, hipStream_t);
+int cac_bwd_spatial(int, int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+int cac_bwd_apply(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
+                  const float*, const float*, const float*, const float*, const float*, const int*,
+                  const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
+int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
 int head_fwd_f32(int, int, int, const float*, int, int, const float*, const float*, float*, hipStream_t);
 int cac_stats_tiles(int, int);
 int cac_stats_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, hipStream_t);
@@ -82,7 +97,9 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
                 "conv2d_fwd: input slice [%d,%d) outside %d channels", d->x_coff, d->x_coff + d->cin, d->x_ctotal);
   CODON_REQUIRE(d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal, CODON_ERR_BAD_ARG,
                 "conv2d_fwd: output slice [%d,%d) outside %d channels", d->y_coff, d->y_coff + d->cout, d->y_ctotal);
-  if (d->flags & CODON_CONV_ADD_RESIDUAL) {
+  CODON_REQUIRE(!((d->flags & CODON_CONV_ADD_RESIDUAL) && (d->flags & CODON_CONV_MASK_RELU)), CODON_ERR_BAD_ARG,
+                "conv2d_fwd: ADD_RESIDUAL and MASK_RELU share the residual slot");
+  if (d->flags & (CODON_CONV_ADD_RESIDUAL | CODON_CONV_MASK_RELU)) {
     CODON_REQUIRE(residual, CODON_ERR_BAD_ARG, "conv2d_fwd: ADD_RESIDUAL without a residual pointer");
     CODON_REQUIRE(d->r_coff >= 0 && d->r_coff + d->cout <= d->r_ctotal, CODON_ERR_BAD_ARG,
                   "conv2d_fwd: residual slice outside its buffer");
@@ -93,13 +110,31 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
                         (hipStream_t)stream);
 }
 
+size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {
+  if (!d || !shape_ok(d->batch, d->height, d->width)) return 0;
+  return conv_wgrad_workspace_bytes(d);
+}
+
+int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, float* dw, void* workspace,
+                       size_t workspace_bytes, int32_t accumulate, codon_stream_t stream) {
+  CODON_REQUIRE(d && x && gy && dw && workspace, CODON_ERR_BAD_ARG, "conv2d_wgrad: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_wgrad: bad shape");
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
+                    d->y_coff + d->cout <= d->y_ctotal,
+                CODON_ERR_BAD_ARG, "conv2d_wgrad: channel slice outside its buffer");
+  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d", d->dtype);
+  return conv2d_wgrad_f32(d, (const float*)x, (const float*)gy, dw, (float*)workspace, workspace_bytes, accumulate,
+                          (hipStream_t)stream);
+}
+
 int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_oihw, void* y,
                    int32_t y_ctotal, int32_t y_coff, int32_t dtype, codon_stream_t stream) {
   CODON_REQUIRE(x && w_oihw && y, CODON_ERR_BAD_ARG, "stem_fwd: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stem_fwd: bad shape");
   CODON_REQUIRE(y_coff >= 0 && y_coff + 64 <= y_ctotal, CODON_ERR_BAD_ARG, "stem_fwd: output slice outside buffer");
   CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
-  return stem_fwd_f32(batch, height, width, x, w_oihw, (float*)y, y_ctotal, y_coff, (hipStream_t)stream);
+  return stem_fwd_f32(batch, height, width, x, w_oihw, (float*)y, y_ctotal, y_coff, 1, nullptr, 0, 0,
+                      (hipStream_t)stream);
 }
 
 int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal, int32_t x_coff,
@@ -154,6 +189,96 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
   CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
   return cac_apply_fwd_f32(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c,
                            (hipStream_t)stream);
+}
+
+int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_64x9,
+                        const codon_tensor* y, int32_t flags, const codon_tensor* mask, int32_t dtype,
+                        codon_stream_t stream) {
+  CODON_REQUIRE(x && w_64x9 && slice_ok(y) && (!mask || slice_ok(mask)), CODON_ERR_BAD_ARG,
+                "stencil_1to64: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stencil_1to64: bad shape");
+  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "stencil_1to64: dtype %d", dtype);
+  return stem_fwd_f32(batch, height, width, x, w_64x9, (float*)y->data, y->ctotal, y->coff, flags,
+                      mask ? (const float*)mask->data : nullptr, mask ? mask->ctotal : 0, mask ? mask->coff : 0,
+                      (hipStream_t)stream);
+}
+
+size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_t width) {
+  if (!shape_ok(batch, height, width)) return 0;
+  return conv1ch_wgrad_workspace_bytes(batch, height, width);
+}
+
+int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a, const float* s,
+                        float* dw, int32_t flip, void* workspace, size_t workspace_bytes, codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(a) && s && dw && workspace, CODON_ERR_BAD_ARG, "conv1ch_wgrad: null pointer or bad slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "conv1ch_wgrad: bad shape");
+  return conv1ch_wgrad(batch, height, width, (const float*)a->data, a->ctotal, a->coff, s, dw, flip,
+                       (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst,
+                      const codon_tensor* src, const codon_tensor* mask, int32_t accumulate, codon_stream_t stream) {
+  auto ok = [&](const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + channels <= t->ctotal; };
+  CODON_REQUIRE(channels > 0 && ok(dst) && (!src || ok(src)) && (!mask || ok(mask)), CODON_ERR_BAD_ARG,
+                "ew_add_mask: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ew_add_mask: bad shape");
+  return ew_add_mask(batch, height, width, channels, dst, src, mask, accumulate, (hipStream_t)stream);
+}
+
+int32_t codon_cac_bwd_tiles(int32_t height, int32_t width) {
+  return (height > 0 && width > 0) ? cac_bwd_tiles(height, width) : 0;
+}
+int32_t codon_cac_bwd_spatial_blocks(int32_t batch, int32_t height, int32_t width) {
+  return shape_ok(batch, height, width) ? cac_bwd_spatial_blocks(batch, height, width) : 0;
+}
+
+int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                         const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                         const float* ch, const float* sp, const float* pools, float* g_z, float* part_gch,
+                         int32_t* part_arg, codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pools &&
+                    g_z && part_gch && part_arg,
+                CODON_ERR_BAD_ARG, "cac_bwd_reduce: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_reduce: bad shape");
+  return cac_bwd_reduce(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg,
+                        (hipStream_t)stream);
+}
+
+int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch, const int32_t* part_arg,
+                       const float* ch, const float* pools, const float* w1, const float* b1, const float* w2,
+                       float* g_pools, int32_t* argpix, float* part_param, float* dw1, float* db1, float* dw2,
+                       float* db2, codon_stream_t stream) {
+  CODON_REQUIRE(part_gch && part_arg && ch && pools && w1 && b1 && w2 && g_pools && argpix && part_param && dw1 &&
+                    db1 && dw2 && db2,
+                CODON_ERR_BAD_ARG, "cac_bwd_gate: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_bwd_gate: bad shape");
+  return cac_bwd_gate(batch, height, width, part_gch, part_arg, ch, pools, w1, b1, w2, g_pools, argpix, part_param,
+                      dw1, db1, dw2, db2, (hipStream_t)stream);
+}
+
+int codon_cac_bwd_spatial(int32_t batch, int32_t height, int32_t width, const float* g_z, const float* pooled,
+                          const float* w_spatial, float* g_pooled, float* part_w, float* dw_spatial,
+                          codon_stream_t stream) {
+  CODON_REQUIRE(g_z && pooled && w_spatial && g_pooled && part_w && dw_spatial, CODON_ERR_BAD_ARG,
+                "cac_bwd_spatial: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_bwd_spatial: bad shape");
+  return cac_bwd_spatial(batch, height, width, g_z, pooled, w_spatial, g_pooled, part_w, dw_spatial,
+                         (hipStream_t)stream);
+}
+
+int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                        const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                        const float* ch, const float* sp, const float* pooled, const float* g_pooled,
+                        const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
+                        const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
+                        int32_t accumulate_in, codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pooled &&
+                    g_pooled && g_pools && argpix && slice_ok(g_pre) && slice_ok(g_pre_c) && slice_ok(g_in) &&
+                    slice_ok(g_in_c),
+                CODON_ERR_BAD_ARG, "cac_bwd_apply: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_apply: bad shape");
+  return cac_bwd_apply(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pooled, g_pooled, g_pools, argpix,
+                       g_pre, g_pre_c, g_in, g_in_c, accumulate_in, (hipStream_t)stream);
 }
 
 int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, int32_t scale, const float* lr,

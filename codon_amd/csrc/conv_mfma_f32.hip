@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
     const bool relu = p.flags & CODON_CONV_RELU;
     const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
     const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
 #pragma unroll
     for (int i = 0; i < PSEG; ++i) {
       const int gy = ty0 + wave * PSEG + i;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
             float v = acc[i][t][r];
             if (relu) v = fmaxf(v, 0.f);
             if (addr) v += rg[co * HW + pix];
+            if (mask) v = rg[co * HW + pix] > 0.f ? v : 0.f;
             if (accum) v += yg[co * HW + pix];
             yg[co * HW + pix] = v;
           }

@@ -36,12 +36,16 @@ __device__ __forceinline__ void load_row(const float* __restrict__ plane, int gy
   v[VEC + 1] = gx0 + VEC < W ? row[gx0 + VEC] : 0.f;
 }
 
+// flags: 1 = ReLU on the output; 2 = use the spatially flipped taps (w[c][8-t]): with w = output.weight
+// this is dL/dt of the head conv (y = sum_c conv3x3(t_c, w_c)) given dL/dy.
+// mask (optional, 64 channels): out = mask > 0 ? out : 0 (backward through conv11's ReLU).
 template <int VEC>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    float* __restrict__ y, int H, int W, long y_img,
-                                                   long y_base, long total) {
+                                                   long y_base, long total, int flags,
+                                                   const float* __restrict__ mask, long m_img, long m_base) {
   __shared__ float wsh[64 * 9];
-  for (int i = threadIdx.x; i < 576; i += 256) wsh[i] = w[i];
+  for (int i = threadIdx.x; i < 576; i += 256) wsh[i] = (flags & 2) ? w[(i / 9) * 9 + 8 - (i % 9)] : w[i];
   __syncthreads();
   const long idx = blockIdx.x * 256L + threadIdx.x;
   if (idx >= total) return;
@@ -58,6 +62,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   load_row<VEC>(plane, gy + 1, gx0, H, W, r2);
   const long HW = (long)H * W;
   float* yo = y + (long)b * y_img + y_base + (long)gy * W + gx0;
+  const float* mo = mask ? mask + (long)b * m_img + m_base + (long)gy * W + gx0 : nullptr;
+  const bool relu = flags & 1;
 #pragma unroll 4
   for (int co = 0; co < 64; ++co) {
     const float* k = wsh + co * 9;
@@ -73,7 +79,16 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
       a = fmaf(k[6], r2[i], a);
       a = fmaf(k[7], r2[i + 1], a);
       a = fmaf(k[8], r2[i + 2], a);
-      o[i] = fmaxf(a, 0.f);
+      o[i] = relu ? fmaxf(a, 0.f) : a;
+    }
+    if (mo) {
+      if constexpr (VEC == 4) {
+        const float4 m = *reinterpret_cast<const float4*>(mo + co * HW);
+        o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
+        o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+      } else {
+        o[0] = mo[co * HW] > 0.f ? o[0] : 0.f;
+      }
     }
     if constexpr (VEC == 4) *reinterpret_cast<float4*>(yo + co * HW) = make_float4(o[0], o[1], o[2], o[3]);
     else yo[co * HW] = o[0];
@@ -133,18 +148,19 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
 }
 
 int stem_fwd_f32(int B, int H, int W, const float* x, const float* w, float* y, int y_ctotal, int y_coff,
-                 hipStream_t stream) {
+                 int flags, const float* mask, int m_ctotal, int m_coff, hipStream_t stream) {
   const long HW = (long)H * W;
-  const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
+  const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                    reinterpret_cast<uintptr_t>(mask)) % 16 == 0);
   const long total = (long)B * H * (v4 ? W / 4 : W);
   const long blocks = (total + 255) / 256;
   CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "stem_fwd: grid too large");
   if (v4)
     hipLaunchKernelGGL(stem_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W, y_ctotal * HW,
-                       y_coff * HW, total);
+                       y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
   else
     hipLaunchKernelGGL(stem_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W, y_ctotal * HW,
-                       y_coff * HW, total);
+                       y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
   return check_launch("stem_kernel");
 }
 
@@ -163,6 +179,88 @@ int head_fwd_f32(int B, int H, int W, const float* x, int x_ctotal, int x_coff, 
     hipLaunchKernelGGL(head_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
                        x_ctotal * HW, x_coff * HW, total);
   return check_launch("head_kernel");
+}
+
+// ---- weight gradient of the 1->64 / 64->1 3x3 convs ----------------------------------------------
+//   R[c][t] = sum_{b,q} A[b,c,q] * s[b, q + (t/3 - 1, t%3 - 1)]        c < 64, t < 9
+//   stem: A = dL/d(conv output, ReLU-masked), s = x      -> input.weight.grad[c][0][t]  = R[c][t]
+//   head: A = t11 (the head's input),         s = dL/dy  -> output.weight.grad[0][c][t] = R[c][8-t]
+// GEMM M = 64 channels, N = 9 taps (padded to 32), K = pixels, on v_mfma_f32_32x32x2_f32 with operands
+// loaded straight from global memory (each 128-byte line of a channel plane is reused by the next
+// 16 k-steps out of L1).  0.01 % of the FLOPs: simplicity over speed.  Per-wave partials -> fixed-order sum.
+constexpr int W1_ROWS = 8;  // image rows per workgroup (2 per wave)
+
+__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restrict__ a, long a_img, long a_base,
+                                                            const float* __restrict__ s, float* __restrict__ part,
+                                                            int H, int W, int nrowblk) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, k = lane >> 5;
+  const int b = blockIdx.x / nrowblk, rb = blockIdx.x % nrowblk;
+  const long HW = (long)H * W;
+  const float* ab = a + b * a_img + a_base;
+  const float* sb = s + (long)b * HW;
+  const int dy = l31 / 3 - 1, dx = l31 % 3 - 1;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int rr = wave; rr < W1_ROWS; rr += 4) {
+    const int y = rb * W1_ROWS + rr;
+    if (y >= H) break;
+    const int yy = y + dy;
+    const bool yok = l31 < 9 && yy >= 0 && yy < H;
+    const float* a0 = ab + (long)l31 * HW + (long)y * W;
+    const float* a1 = a0 + 32 * HW;
+    const float* srow = sb + (long)yy * W;
+    for (int x0 = 0; x0 < W; x0 += 2) {
+      const int x = x0 + k;
+      const bool xin = x < W;
+      const float va0 = xin ? a0[x] : 0.f;
+      const float va1 = xin ? a1[x] : 0.f;
+      const int xx = x + dx;
+      const float vb = (yok && xin && xx >= 0 && xx < W) ? srow[xx] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc1, 0, 0, 0);
+    }
+  }
+  if (l31 < 9) {
+    float* o = part + ((long)blockIdx.x * 4 + wave) * 576;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * k;
+      o[c * 9 + l31] = acc0[r];
+      o[(32 + c) * 9 + l31] = acc1[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dw, int nparts, int flip,
+                                                                   int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 576) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * 576 + i];
+  const int o = flip ? (i / 9) * 9 + 8 - (i % 9) : i;
+  dw[o] = accumulate ? dw[o] + s : s;
+}
+
+size_t conv1ch_wgrad_workspace_bytes(int B, int H, int W) {
+  const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
+  return (size_t)B * nrowblk * 4 * 576 * sizeof(float);
+}
+
+int conv1ch_wgrad(int B, int H, int W, const float* a, int a_ctotal, int a_coff, const float* s, float* dw, int flip,
+                  float* ws, size_t ws_bytes, hipStream_t stream) {
+  CODON_REQUIRE(ws_bytes >= conv1ch_wgrad_workspace_bytes(B, H, W), CODON_ERR_BAD_ARG,
+                "conv1ch_wgrad: workspace too small");
+  const long HW = (long)H * W;
+  const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
+  hipLaunchKernelGGL(conv1ch_wgrad_kernel, dim3(B * nrowblk), dim3(256), 0, stream, a, a_ctotal * HW, a_coff * HW, s,
+                     ws, H, W, nrowblk);
+  int st = check_launch("conv1ch_wgrad_kernel");
+  if (st != CODON_OK) return st;
+  hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(3), dim3(256), 0, stream, ws, dw, B * nrowblk * 4, flip, 0);
+  return check_launch("conv1ch_wgrad_reduce_kernel");
 }
 
 }  // namespace codon

@@ -84,13 +84,21 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
 
 
 def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = False,
-           residual: Optional[Slice] = None, accumulate: bool = False):
+           residual: Optional[Slice] = None, accumulate: bool = False, relu_mask: Optional[Slice] = None):
+    """y = conv(x) [relu] [+ residual] ; relu_mask: y = (relu_mask > 0) ? conv(x) : 0 (backward through a
+    ReLU given its output); accumulate: y += result."""
+    if relu_mask is not None:
+        assert residual is None
+        residual = relu_mask
     lib = L.load()
     dev = _dev(x.buf, w_packed, y.buf, residual.buf if residual else None)
     B, _, H, W = x.buf.shape
     assert y.buf.shape[0] == B and y.buf.shape[2:] == x.buf.shape[2:]
-    flags = (L.CONV_RELU if relu else 0) | (L.CONV_ADD_RESIDUAL if residual is not None else 0) | \
-            (L.CONV_ACCUM_OUT if accumulate else 0)
+    flags = (L.CONV_RELU if relu else 0) | (L.CONV_ACCUM_OUT if accumulate else 0)
+    if relu_mask is not None:
+        flags |= L.CONV_MASK_RELU
+    elif residual is not None:
+        flags |= L.CONV_ADD_RESIDUAL
     d = L.ConvDesc(B, H, W, x.c, y.c, ksize, x.ctotal, x.coff, y.ctotal, y.coff,
                    residual.ctotal if residual else 0, residual.coff if residual else 0, flags, _dt(x.buf))
     if residual is not None:
@@ -105,6 +113,22 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
         if prof is not None:
             e1.record(torch.cuda.current_stream(dev))
             prof["events"].append((e0, e1))
+
+
+def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: bool = False):
+    """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy."""
+    lib = L.load()
+    dev = _dev(x.buf, gy.buf, dw)
+    B, _, H, W = x.buf.shape
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, ksize, ksize)
+    d = L.ConvDesc(B, H, W, x.c, gy.c, ksize, x.ctotal, x.coff, gy.ctotal, gy.coff, 0, 0, 0, _dt(x.buf))
+    nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(f"codon_amd: no wgrad kernel for k={ksize} cin={x.c} cout={gy.c}")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_conv2d_wgrad(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(dw), _ptr(ws), nbytes,
+                                       1 if accumulate else 0, _stream(dev)), "conv2d_wgrad")
 
 
 def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
@@ -170,3 +194,82 @@ def cac_apply(pre: Slice, pre_c: Slice, ch, sp, inputs: Slice, inputs_c: Slice, 
         L.check(lib.codon_cac_apply_fwd(B, H, W, C.byref(ts[0]), C.byref(ts[1]), _ptr(ch), _ptr(sp),
                                         C.byref(ts[2]), C.byref(ts[3]), C.byref(ts[4]), C.byref(ts[5]),
                                         _dt(pre.buf), _stream(dev)), "cac_apply_fwd")
+
+
+# ---- backward -------------------------------------------------------------------------------------
+
+def stencil_1to64(x: torch.Tensor, w: torch.Tensor, y: Slice, relu: bool = False, flip: bool = False,
+                  mask: Optional[Slice] = None):
+    lib = L.load()
+    dev = _dev(x, w, y.buf, mask.buf if mask else None)
+    B, _, H, W = x.shape
+    assert y.c == 64 and w.numel() == 576 and w.dtype == torch.float32 and x.dtype == torch.float32
+    yt = y.ct()
+    mt = mask.ct() if mask is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.codon_stencil_1to64(B, H, W, _ptr(x), _ptr(w), C.byref(yt), (1 if relu else 0) | (2 if flip else 0),
+                                        C.byref(mt) if mt is not None else None, _dt(y.buf), _stream(dev)),
+                "stencil_1to64")
+
+
+def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: torch.Tensor, flip: bool):
+    lib = L.load()
+    dev = _dev(a.buf, s, dw)
+    B, _, H, W = a.buf.shape
+    assert a.c == 64 and dw.numel() == 576 and dw.dtype == torch.float32 and s.shape[1] == 1
+    nbytes = lib.codon_conv1ch_wgrad_workspace_bytes(B, H, W)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    at = a.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_conv1ch_wgrad(B, H, W, C.byref(at), _ptr(s), _ptr(dw), 1 if flip else 0, _ptr(ws), nbytes,
+                                        _stream(dev)), "conv1ch_wgrad")
+
+
+def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] = None, accumulate: bool = True):
+    lib = L.load()
+    dev = _dev(dst.buf, src.buf if src else None, mask.buf if mask else None)
+    B, _, H, W = dst.buf.shape
+    dt_, st_, mt_ = dst.ct(), (src.ct() if src else None), (mask.ct() if mask else None)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_ew_add_mask(B, H, W, dst.c, C.byref(dt_), C.byref(st_) if st_ is not None else None,
+                                      C.byref(mt_) if mt_ is not None else None, 1 if accumulate else 0,
+                                      _stream(dev)), "ew_add_mask")
+
+
+def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
+                 g_pre: Slice, g_pre_c: Slice, g_in: Slice, g_in_c: Slice, accumulate_in: bool):
+    """Full backward of one CAC gate block.  Returns (dw1, db1, dw2, db2, dws) fp32 tensors."""
+    lib = L.load()
+    dev = _dev(g_out.buf, g_out_c.buf, pre.buf, pre_c.buf, ch, sp, pooled, pools, w1, b1, w2, ws, g_pre.buf,
+               g_pre_c.buf, g_in.buf, g_in_c.buf)
+    B, _, H, W = pre.buf.shape
+    f32 = dict(dtype=torch.float32, device=dev)
+    nt = lib.codon_cac_bwd_tiles(H, W)
+    nsb = lib.codon_cac_bwd_spatial_blocks(B, H, W)
+    g_z = torch.empty((B, 1, H, W), **f32)
+    part_gch = torch.empty((B, nt, 64), **f32)
+    part_arg = torch.empty((B, nt, 128), dtype=torch.int32, device=dev)
+    g_pools = torch.empty((B, 2, 128), **f32)
+    argpix = torch.empty((B, 128), dtype=torch.int32, device=dev)
+    part_param = torch.empty((B, 1608), **f32)
+    dw1, db1 = torch.empty((8, 128), **f32), torch.empty((8,), **f32)
+    dw2, db2 = torch.empty((64, 8), **f32), torch.empty((64,), **f32)
+    g_pooled = torch.empty((B, 2, H, W), **f32)
+    part_w = torch.empty((nsb, 50), **f32)
+    dws = torch.empty((1, 2, 5, 5), **f32)
+    t = [s.ct() for s in (g_out, g_out_c, pre, pre_c, g_pre, g_pre_c, g_in, g_in_c)]
+    st = _stream(dev)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_bwd_reduce(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]),
+                                         _ptr(ch), _ptr(sp), _ptr(pools), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
+                                         st), "cac_bwd_reduce")
+        L.check(lib.codon_cac_bwd_gate(B, H, W, _ptr(part_gch), _ptr(part_arg), _ptr(ch), _ptr(pools), _ptr(w1),
+                                       _ptr(b1), _ptr(w2), _ptr(g_pools), _ptr(argpix), _ptr(part_param), _ptr(dw1),
+                                       _ptr(db1), _ptr(dw2), _ptr(db2), st), "cac_bwd_gate")
+        L.check(lib.codon_cac_bwd_spatial(B, H, W, _ptr(g_z), _ptr(pooled), _ptr(ws), _ptr(g_pooled), _ptr(part_w),
+                                          _ptr(dws), st), "cac_bwd_spatial")
+        L.check(lib.codon_cac_bwd_apply(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]),
+                                        _ptr(ch), _ptr(sp), _ptr(pooled), _ptr(g_pooled), _ptr(g_pools),
+                                        _ptr(argpix), C.byref(t[4]), C.byref(t[5]), C.byref(t[6]), C.byref(t[7]),
+                                        1 if accumulate_in else 0, st), "cac_bwd_apply")
+    return dw1, db1, dw2, db2, dws

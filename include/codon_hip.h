@@ -38,7 +38,9 @@ typedef enum codon_dtype { CODON_F32 = 0, CODON_BF16 = 1 } codon_dtype;
 enum {
   CODON_CONV_RELU = 1,         /* y = max(conv, 0)          (self.relu(self.convN(..)))      */
   CODON_CONV_ADD_RESIDUAL = 2, /* y = conv + residual       (torch.add(out_fuse, fuse) :128) */
-  CODON_CONV_ACCUM_OUT = 4     /* y += conv                 (backward: grads that fan in)    */
+  CODON_CONV_ACCUM_OUT = 4,    /* y += conv                 (backward: grads that fan in)    */
+  CODON_CONV_MASK_RELU = 8     /* y = residual > 0 ? conv : 0   (backward through a ReLU whose OUTPUT is
+                                  passed in the residual slot; applied before ACCUM_OUT's add)      */
 };
 
 enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1 };
@@ -82,6 +84,17 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
 int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
                      const void* residual, codon_stream_t stream);
 
+/* dL/dw (cout, cin, k, k) fp32 = sum over b,h,w of gy[b,co,h,w] * x[b,ci,h+dy-p,w+dx-p]: what autograd
+ * computes for the nn.Conv2d weights (the reference has no explicit backward).
+ * d describes the FORWARD conv: x = its input (x_* fields), gy = gradient of its output (y_* fields
+ * describe gy's buffer).  workspace: codon_conv_wgrad_workspace_bytes(d) bytes of scratch (per-split
+ * partials, summed in fixed order: deterministic).  The result is ADDED into dw when accumulate != 0
+ * (weights shared by the 5 / 3 loop iterations, CODON_x4.py:74,122). */
+size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d);
+int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, float* dw,
+                       void* workspace, size_t workspace_bytes, int32_t accumulate,
+                       codon_stream_t stream);
+
 /* ---- stem / head stencils (HBM-bound) ----------------------------------------------------
  * stem: y[:, y_coff:y_coff+64] = relu(conv3x3_{1->64}(x))        CODON_x4.py:68,71
  * head: y = conv3x3_{64->1}(x) + residual                         CODON_x4.py:130-131 */
@@ -121,6 +134,61 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
                         const codon_tensor* inputs, const codon_tensor* inputs_c,
                         const codon_tensor* out, const codon_tensor* out_c, int32_t dtype,
                         codon_stream_t stream);
+
+/* ---- backward (what torch.autograd computes for the reference) ------------
+ * The MFMA convs back-propagate through codon_conv2d_fwd (CODON_PACK_DGRAD weights, MASK_RELU /
+ * ACCUM_OUT epilogues) and codon_conv2d_wgrad above; the entry points below cover the rest. */
+
+/* Generalised 1->64 3x3 stencil.  flags: 1 = ReLU, 2 = spatially flipped taps.
+ * flags=1           : the stem forward (== codon_stem_fwd)
+ * flags=2, w=output.weight, x=dL/dy, mask=t11 : dL/dt11 of the head conv, masked by conv11's ReLU
+ *                     (backward of CODON_x4.py:129-130). mask may be NULL. */
+int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const float* x,
+                        const float* w_64x9, const codon_tensor* y, int32_t flags,
+                        const codon_tensor* mask, int32_t dtype, codon_stream_t stream);
+
+/* dw[c*9 + t] = sum_{b,q} a[b,c,q] * s[b, q + (t/3-1, t%3-1)]   (flip: written at c*9 + 8-t)
+ * stem: a = dL/d(stem output, ReLU-masked), s = x, flip=0  -> input.weight.grad (64,1,3,3)
+ * head: a = t11, s = dL/dy, flip=1                         -> output.weight.grad (1,64,3,3) */
+size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_t width);
+int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a,
+                        const float* s, float* dw, int32_t flip, void* workspace,
+                        size_t workspace_bytes, codon_stream_t stream);
+
+/* dst = [dst +] src (src may be NULL), then dst = mask > 0 ? dst : 0 (mask may be NULL); C channels. */
+int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels,
+                      const codon_tensor* dst, const codon_tensor* src, const codon_tensor* mask,
+                      int32_t accumulate, codon_stream_t stream);
+
+/* CAC gate backward, four launches (see codon_amd/csrc/cac_bwd.hip for the math):
+ * reduce : g_z (B,1,H,W) = dL/d(spatial logits); part_gch (B,nt,64), part_arg (B,nt,128) int32,
+ *          nt = codon_cac_bwd_tiles(H,W).  pools = the (B,2,128) {avg,max} saved by cac_gate_fwd.
+ * gate   : g_pools (B,2,128) = dL/d{avg,max}; argpix (B,128) int32 first arg-max pixel of each Fcat
+ *          channel; part_param (B,1608) scratch; dw1 (8,128), db1 (8), dw2 (64,8), db2 (64) OVERWRITTEN.
+ * spatial: g_pooled (B,2,H,W) = dL/d{chmax,chmean}; part_w (codon_cac_bwd_spatial_blocks(B,H,W),50)
+ *          scratch; dw (1,2,5,5) OVERWRITTEN.
+ * apply  : g_pre / g_pre_c = full dL/dpre, dL/dpre_c; g_in / g_in_c (+)= g_out / g_out_c
+ *          (accumulate_in = 0 writes instead of adding). */
+int32_t codon_cac_bwd_tiles(int32_t height, int32_t width);
+int32_t codon_cac_bwd_spatial_blocks(int32_t batch, int32_t height, int32_t width);
+int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                         const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                         const float* ch, const float* sp, const float* pools, float* g_z,
+                         float* part_gch, int32_t* part_arg, codon_stream_t stream);
+int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch,
+                       const int32_t* part_arg, const float* ch, const float* pools, const float* w1,
+                       const float* b1, const float* w2, float* g_pools, int32_t* argpix,
+                       float* part_param, float* dw1, float* db1, float* dw2, float* db2,
+                       codon_stream_t stream);
+int codon_cac_bwd_spatial(int32_t batch, int32_t height, int32_t width, const float* g_z,
+                          const float* pooled, const float* w_spatial, float* g_pooled, float* part_w,
+                          float* dw_spatial, codon_stream_t stream);
+int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                        const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                        const float* ch, const float* sp, const float* pooled, const float* g_pooled,
+                        const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
+                        const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
+                        int32_t accumulate_in, codon_stream_t stream);
 
 /* ---- synthetic-input generator: x4 / x8 / x16 bicubic upsample ---------------------------------
  * No reference counterpart (the reference's depth inputs are upsampled offline,

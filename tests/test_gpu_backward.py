@@ -1,0 +1,141 @@
+"""Backward parity (row a15): HIP gradients through the C ABI vs (1) autograd gradients recorded from
+the imported reference (tests/golden, L1 loss) and (2) the CPU oracle's autograd on fresh inputs.
+Tolerance: per-tensor rel-RMSE <= 1e-4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import codon_oracle as orc
+from tests.util import load_case, rel_rmse, rmse, target_for
+
+GRAD_TOL = 1e-4
+
+
+def _model(variant, sd):
+    from codon_amd import CODONNet, CODONNet16
+    m = (CODONNet16 if variant == "x16" else CODONNet)()
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train()
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(size=shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 48, 64), (1, 1, 1), (2, 50, 41)])
+def test_cac_backward_vs_autograd(shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = torch.device("cuda:0")
+    B, H, W = shape
+    pre2 = _rand((B, 128, H, W), 1).requires_grad_(True)       # [pre | pre_c]
+    in2 = _rand((B, 128, H, W), 2)
+    w1, b1 = _rand((8, 128), 3, 0.1).requires_grad_(True), _rand((8,), 4, 0.1).requires_grad_(True)
+    w2, b2 = _rand((64, 8), 5, 0.3).requires_grad_(True), _rand((64,), 6, 0.1).requires_grad_(True)
+    ws = _rand((1, 2, 5, 5), 7, 0.2).requires_grad_(True)
+    g_oc = _rand((B, 128, H, W), 8)
+    pre, pre_c = pre2[:, :64], pre2[:, 64:]
+    Fcat = torch.cat((pre_c, pre), 1)
+    ch = orc.cac_channel(Fcat, w1, b1, w2, b2)
+    sp = orc.cac_spatial(Fcat, ws)
+    g = ch[:, :, None, None] * sp
+    oc = torch.cat((pre * g + in2[:, :64], pre_c * g + in2[:, 64:]), 1)
+    oc.backward(g_oc)
+
+    d = lambda t: t.detach().to(dev).contiguous()
+    p2 = d(pre2)
+    nt = ops.cac_stats_tiles(H, W)
+    pooled = torch.empty((B, 2, H, W), device=dev)
+    partials = torch.empty((B, nt, 128, 2), device=dev)
+    chd = torch.empty((B, 64), device=dev)
+    pools = torch.empty((B, 2, 128), device=dev)
+    spd = torch.empty((B, 1, H, W), device=dev)
+    ops.cac_stats(Slice(p2, 64, 64), Slice(p2, 0, 64), pooled, partials)
+    ops.cac_gate(B, H, W, partials, d(w1), d(b1), d(w2), d(b2), chd, pools)
+    ops.cac_spatial(pooled, d(ws), spd)
+    gocd = d(g_oc)
+    g_pre2 = torch.empty((B, 128, H, W), device=dev)
+    base = _rand((B, 128, H, W), 9)
+    g_in2 = base.to(dev)
+    dw1, db1, dw2, db2, dws = ops.cac_backward(
+        Slice(gocd, 0, 64), Slice(gocd, 64, 64), Slice(p2, 0, 64), Slice(p2, 64, 64), chd, spd, pooled, pools,
+        d(w1), d(b1), d(w2), d(ws), Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64),
+        Slice(g_in2, 64, 64), accumulate_in=True)
+    assert rel_rmse(g_pre2.cpu(), pre2.grad) < 1e-5
+    assert rel_rmse(g_in2.cpu(), base + g_oc) < 1e-6
+    for got, ref, nm in ((dw1, w1.grad, "w1"), (db1, b1.grad, "b1"), (dw2, w2.grad, "w2"), (db2, b2.grad, "b2"),
+                         (dws, ws.grad, "ws")):
+        assert rel_rmse(got.cpu(), ref) < 2e-5, nm
+
+
+def test_stencil_backward_pieces():
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = torch.device("cuda:0")
+    for (B, H, W) in [(2, 19, 45), (1, 16, 64), (1, 1, 1), (1, 9, 3)]:
+        # head: y = conv(t, w_out) + x
+        t = torch.relu(_rand((B, 64, H, W), 1)).requires_grad_(True)
+        wo = _rand((1, 64, 3, 3), 2, 0.1).requires_grad_(True)
+        gy = _rand((B, 1, H, W), 3)
+        F.conv2d(t, wo, None, 1, 1).backward(gy)
+        g_t = torch.empty((B, 64, H, W), device=dev)
+        ops.stencil_1to64(gy.to(dev), wo.detach().to(dev), Slice(g_t), flip=True, mask=Slice(t.detach().to(dev)))
+        assert rel_rmse(g_t.cpu(), t.grad * (t.detach() > 0)) < 1e-6
+        dwo = torch.empty((1, 64, 3, 3), device=dev)
+        ops.conv1ch_wgrad(Slice(t.detach().to(dev)), gy.to(dev), dwo, flip=True)
+        assert rel_rmse(dwo.cpu(), wo.grad) < 3e-6
+        # stem: s = conv(x, w_in)
+        x = _rand((B, 1, H, W), 4)
+        wi = _rand((64, 1, 3, 3), 5, 0.3).requires_grad_(True)
+        gs = _rand((B, 64, H, W), 6)
+        F.conv2d(x, wi, None, 1, 1).backward(gs)
+        dwi = torch.empty((64, 1, 3, 3), device=dev)
+        ops.conv1ch_wgrad(Slice(gs.to(dev)), x.to(dev), dwi, flip=False)
+        assert rel_rmse(dwi.cpu(), wi.grad) < 3e-6
+
+
+@pytest.mark.parametrize("name", ["kat0_x4_2x32x24", "kat0_x16_2x20x28", "he0_x4_2x24x20_taps"])
+def test_gradients_match_reference_golden(name):
+    z, variant, sd, x, y = load_case(name)
+    m = _model(variant, sd)
+    out = m(x.cuda(), y.cuda())
+    loss = (out - target_for(x).cuda()).abs().mean()
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * max(1.0, abs(float(z["loss"])))
+    n = 0
+    for k, p in m.named_parameters():
+        if k.startswith("attention_c5") or k.startswith("attention_s5"):
+            assert p.grad is None
+            continue
+        stride = int(z["gradstride." + k])
+        got = p.grad.flatten()[::stride].cpu()
+        assert rel_rmse(got, z["grad." + k]) <= GRAD_TOL, k
+        nrm = float(z["gradnorm." + k])
+        assert abs(float(p.grad.double().norm()) - nrm) <= 1e-4 * nrm + 1e-12, k
+        n += 1
+    assert n == 44
+
+
+def test_gradients_match_oracle_autograd_random():
+    sd = orc.he_state("x4", seed=21)
+    g = np.random.default_rng(4)
+    B, H, W = 2, 37, 53
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    tgt = target_for(x)
+    loss_ref, gref, out_ref = orc.grads(sd, x, y, tgt)
+    m = _model("x4", sd)
+    out = m(x.cuda(), y.cuda())
+    assert rmse(out.detach().cpu(), out_ref) <= 1e-4
+    loss = (out - tgt.cuda()).abs().mean()
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k in gref:
+            assert rel_rmse(p.grad.cpu(), gref[k]) <= GRAD_TOL, k
+    # a second backward accumulates into .grad like any autograd parameter
+    out2 = m(x.cuda(), y.cuda())
+    (out2 - tgt.cuda()).abs().mean().backward()
+    assert rel_rmse(m.conv3.weight.grad.cpu(), 2 * gref["conv3.weight"]) <= GRAD_TOL

@@ -158,3 +158,66 @@ def test_error_conventions():
         ops.conv2d(Slice(x), torch.zeros(48 * 64 * 9, device=dev), Slice(y), 3)
     with pytest.raises(RuntimeError, match="HIP device"):
         ops.conv2d(Slice(x.cpu()), torch.zeros(8), Slice(y.cpu()), 3)
+
+
+WGRAD_CASES = [(5, 128, 128), (5, 64, 64), (3, 64, 64), (3, 128, 64), (1, 128, 64)]
+
+
+@pytest.mark.parametrize("k,cin,cout", WGRAD_CASES)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70)])
+def test_conv2d_wgrad_vs_autograd(k, cin, cout, shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, cin, H, W), 1)
+    w = _rand((cout, cin, k, k), 2, 0.05).requires_grad_(True)
+    gy = _rand((B, cout, H, W), 3)
+    F.conv2d(x, w, None, 1, k // 2).backward(gy)
+    dw = torch.full((cout, cin, k, k), float("nan"), device=dev)
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k)
+    assert rel_rmse(dw.cpu(), w.grad) < 3e-6
+    # accumulate (shared weights): dw += same again
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k, accumulate=True)
+    assert rel_rmse(dw.cpu(), 2 * w.grad) < 3e-6
+    # deterministic: fixed-order reduction
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw2, k)
+    dw3 = torch.empty_like(dw)
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw3, k)
+    assert torch.equal(dw2, dw3)
+
+
+def test_conv2d_wgrad_slices_and_bands():
+    """Channel slices of wider buffers + an image tall enough to be split into several bands."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 1, 130, 40
+    xb = _rand((B, 128, H, W), 1)
+    gb = _rand((B, 128, H, W), 2)
+    w = torch.zeros((64, 64, 5, 5), requires_grad=True)
+    F.conv2d(xb[:, 64:], w, None, 1, 2).backward(gb[:, :64])
+    dw = torch.empty((64, 64, 5, 5), device=dev)
+    ops.conv2d_wgrad(Slice(xb.to(dev), 64, 64), Slice(gb.to(dev), 0, 64), dw, 5)
+    assert rel_rmse(dw.cpu(), w.grad) < 3e-6
+
+
+def test_conv2d_relu_mask_and_accumulate():
+    """dgrad through a ReLU: gx = (x_saved > 0) ? conv(gy, w') : 0, accumulated into a fan-in buffer."""
+    from codon_amd import _lib as L
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 11, 37
+    xs = torch.relu(_rand((B, 64, H, W), 1))
+    w = _rand((64, 64, 3, 3), 2, 0.1)
+    gy = _rand((B, 64, H, W), 3)
+    xv = xs.clone().requires_grad_(True)
+    F.conv2d(xv, w, None, 1, 1).backward(gy)
+    ref = xv.grad * (xs > 0)
+    base = _rand((B, 64, H, W), 4)
+    out = base.to(dev)
+    ops.conv2d(Slice(gy.to(dev)), ops.packed_weight(w.to(dev), L.PACK_DGRAD), Slice(out), 3,
+               relu_mask=Slice(xs.to(dev)), accumulate=True)
+    assert rel_rmse(out.cpu(), base + ref) < 2e-6

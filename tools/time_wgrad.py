@@ -1,0 +1,21 @@
+import sys, torch, time
+sys.path.insert(0, "/root/repo")
+from codon_amd import ops
+from codon_amd.ops import Slice
+dev = torch.device("cuda:0")
+B, H, W = 32, 480, 640
+for (k, ci, co) in [(5, 128, 128), (5, 64, 64), (3, 64, 64), (1, 128, 64)]:
+    x = torch.randn((B, ci, H, W), device=dev)
+    g = torch.randn((B, co, H, W), device=dev)
+    dw = torch.empty((co, ci, k, k), device=dev)
+    ops.conv2d_wgrad(Slice(x), Slice(g), dw, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        ops.conv2d_wgrad(Slice(x), Slice(g), dw, k)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    fl = 2.0 * k * k * ci * co * B * H * W
+    print(f"wgrad k{k} {ci}->{co}: {ms:.2f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+    del x, g
