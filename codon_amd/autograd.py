@@ -60,7 +60,7 @@ def codon_apply(model, x, y):
     return _CodonFn.apply(model, x, y, *params)
 
 
-def _backward_impl(model, S, x, y, gy):
+def _backward_impl(model, S, x, y, gy, debug=None):
     B, _, H, W = x.shape
     dev = x.device
     new = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
@@ -125,6 +125,8 @@ def _backward_impl(model, S, x, y, gy):
         Bk = S[f"blk{i}"]
         xin, stage, r2, stage_c, r2_c, pre2 = Bk["x"], Bk["stage"], Bk["r2"], Bk["stage_c"], Bk["r2_c"], Bk["pre2"]
         ac, asp = getattr(model, f"attention_c{i}"), getattr(model, f"attention_s{i}")
+        if debug is not None:
+            debug[f"g_oc{i}"] = g_oc.clone()
         dw1, db1, dw2, db2, dws = ops.cac_backward(
             Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
             Bk["pooled"], Bk["pools"], ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight, asp.spatial.conv.weight,

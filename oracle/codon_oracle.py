@@ -177,6 +177,9 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
         stage_c = torch.cat((R1_c, P1_c), 1)                      # :80  5x5 | 3x3
         R2 = r(_conv(stage, w("conv3")))                          # :81
         R2_c = r(_conv(stage_c, w("conv6")))                      # :82
+        if taps is not None:
+            taps[f"blk{i}.stage"], taps[f"blk{i}.stage_c"] = stage, stage_c
+            taps[f"blk{i}.r2"], taps[f"blk{i}.r2_c"] = R2, R2_c
         out_c = _conv(R2_c, w("confuse_c"))                       # :83
         out = _conv(R2, w("confuse"))                             # :84
         Fcat = torch.cat((out_c, out), 1)                         # :85  colour | depth
@@ -197,10 +200,13 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
         taps["fuse"] = fuse
     for i in range(3):
         st = torch.cat((r(_conv(f, w("conv8"))), r(_conv(f, w("conv9")))), 1)   # :123-125
-        f = _conv(r(_conv(st, w("conv10"))), w("confuse_fuse")) + fuse          # :126-128
+        r2 = r(_conv(st, w("conv10")))                                          # :126
+        f = _conv(r2, w("confuse_fuse")) + fuse                                 # :127-128
         if taps is not None:
-            taps[f"trunk{i}"] = f
+            taps[f"trunk{i}"], taps[f"trunk{i}.stage"], taps[f"trunk{i}.r2"] = f, st, r2
     out = r(_conv(f, w("conv11")))                                # :129
+    if taps is not None:
+        taps["t11"] = out
     return _conv(out, w("output")) + residual                     # :130-132
 
 

