@@ -192,3 +192,30 @@ def test_gradients_match_oracle_autograd_random():
     out2 = m(x.cuda(), y.cuda())
     out2.backward(g_up)
     assert rel_rmse(m.conv3.weight.grad.cpu(), 2 * gref["conv3.weight"]) <= GRAD_TOL
+
+
+def test_gradsync_flat_views_accumulate_in_place():
+    """Autograd must accumulate into the flat-buffer views GradSync installs (no re-allocation of .grad),
+    and an Adam step through those views must change the parameters."""
+    from codon_amd.dist import GradSync
+    sd = orc.he_state("x4", seed=5)
+    m = _model("x4", sd)
+    gs = GradSync(m)
+    x, y = orc.kat_inputs(2, 16, 24)
+    tgt = target_for(x).cuda()
+    opt = torch.optim.Adam(gs.params, lr=1e-3)
+    gs.zero_grad()
+    (m(x.cuda(), y.cuda()) - tgt).abs().mean().backward()
+    assert m.conv3.weight.grad._base is gs.flat and float(gs.flat.abs().sum()) > 0
+    n1 = float(gs.flat.norm())
+    (m(x.cuda(), y.cuda()) - tgt).abs().mean().backward()         # second backward accumulates
+    assert abs(float(gs.flat.norm()) - 2 * n1) < 1e-4 * n1
+    w0 = m.conv3.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(w0, m.conv3.weight)
+    # packed-weight cache notices the in-place update (version counter) -> next forward uses new weights
+    o1 = m(x.cuda(), y.cuda())
+    m2 = _model("x4", {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        o2 = m2(x.cuda(), y.cuda())
+    assert torch.equal(o1.detach(), o2)
