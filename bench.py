@@ -29,6 +29,7 @@ FLOP_PER_PIXEL_FWD = 14_856_052          # 2 x 7 428 026 MAC
 ALG_ELEMS_PER_PIXEL = 12_706             # activation elements moved per output pixel
 CONV5_128_MAC_PER_PIXEL = 409_600        # 5*5*128*128
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -153,6 +154,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8, 16])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: BASELINE configs[1] (default); bf16: bf16 activations/weights, fp32 accumulate + master weights")
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd: BASELINE metric (maps/s); train: fwd + L1 loss + bwd + grad all-reduce + Adam step (iters/s)")
     a = ap.parse_args()
@@ -176,6 +179,11 @@ def main():
     B, H, W = a.batch, a.height, a.width
     torch.manual_seed(0)
     model = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev).eval()   # reference init rule, seed 0
+    bf16 = a.dtype == "bf16"
+    if bf16:
+        model.set_compute_dtype(torch.bfloat16)
+    esize = 2 if bf16 else 4
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     x, y = synth_inputs(B, H, W, a.scale, 1234 + rank, dev)
 
     def barrier():
@@ -216,25 +224,25 @@ def main():
         res = {
             "metric": "HR depth maps/sec (fwd)", "value": maps_s, "unit": "maps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"CODON x{a.scale} forward, batch {B}/GPU at {H}x{W}, fp32 "
-                                   f"(BASELINE.json configs[1])" if (B, H, W, a.scale) == (32, 480, 640, 4)
-                       else f"CODON x{a.scale} forward, batch {B}/GPU at {H}x{W}, fp32",
+                                   f"(BASELINE.json configs[1])" if (B, H, W, a.scale, bf16) == (32, 480, 640, 4, False)
+                       else f"CODON x{a.scale} forward, batch {B}/GPU at {H}x{W}, {a.dtype}",
                        "batch_per_gpu": B, "height": H, "width": W,
                        "parallelism": f"dp{world}: images sharded across ranks, no collective in forward",
                        "weights": "reference init rule (He-normal convs, default CAC), torch.manual_seed(0)"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<5,128,128> (conv3/conv6/conv10)",
-                         "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("codon::conv_mfma_f32_kernel<5, 128, 128", B, H, W),
+            "roofline": {"bound": "mfma", "kernel": f"conv_mfma_{a.dtype}_kernel<5,128,128> (conv3/conv6/conv10)",
+                         "achieved": ach, "peak": peak_mfma, "unit": "TFLOP/s",
+                         "frac": ach / peak_mfma,
+                         "traffic": None if bf16 else pmc_traffic("codon::conv_mfma_f32_kernel<5, 128, 128", B, H, W),
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                         "alg_bytes_per_launch": 2 * 128 * 4 * P,
+                         "alg_bytes_per_launch": 2 * 128 * esize * P,
                          "launches_timed": len(ev), "avg_launch_ms": kms,
                          "flop_per_launch": kflop},
             "whole_forward": {"tflops": FLOP_PER_PIXEL_FWD * P / step_s / 1e12,
-                              "frac_f32_mfma_peak": FLOP_PER_PIXEL_FWD * P / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                              "alg_hbm_gbs": ALG_ELEMS_PER_PIXEL * 4 * P / step_s / 1e9,
-                              "frac_hbm_peak": ALG_ELEMS_PER_PIXEL * 4 * P / step_s / 1e9 / PEAK_HBM_GBS,
+                              "frac_mfma_peak": FLOP_PER_PIXEL_FWD * P / step_s / 1e12 / peak_mfma,
+                              "alg_hbm_gbs": ALG_ELEMS_PER_PIXEL * esize * P / step_s / 1e9,
+                              "frac_hbm_peak": ALG_ELEMS_PER_PIXEL * esize * P / step_s / 1e9 / PEAK_HBM_GBS,
                               "mpx_per_s": world * P / step_s / 1e6},
         }
         if world == 1 and not a.no_cpu_baseline:

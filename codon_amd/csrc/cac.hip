@@ -11,10 +11,11 @@
 #include <math.h>
 
 #include "codon_common.h"
+#include "px8.h"
 
 namespace codon {
 
-constexpr int STATS_TILE = 2048;  // pixels per workgroup (8 per thread)
+constexpr int STATS_TILE = PX_TILE;  // pixels per workgroup (8 per thread)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -27,50 +28,35 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// grid = (ntiles, B).  Thread t owns pixels  tile0 + j*1024 + t*4 + {0..3}, j = 0,1  (VEC = 4)
-//                                   or      tile0 + j*256 + t,            j = 0..7  (VEC = 1).
-template <int VEC>
-__global__ __launch_bounds__(256) void cac_stats_kernel(const float* __restrict__ pre_c, long pc_img,
-                                                        const float* __restrict__ pre, long p_img,
+// grid = (ntiles, B).  P = pixel-ownership policy (px8.h): 8 pixels per thread, widest coalesced access.
+template <class P>
+__global__ __launch_bounds__(256) void cac_stats_kernel(const typename P::T* __restrict__ pre_c, long pc_img,
+                                                        const typename P::T* __restrict__ pre, long p_img,
                                                         float* __restrict__ pooled, float* __restrict__ partials,
                                                         long HW, int ntiles) {
-  constexpr int NJ = 8 / VEC;
   __shared__ float red[128][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, b = blockIdx.y;
-  const long tile0 = (long)tile * STATS_TILE;
-  long pix[NJ];
-  bool ok[NJ];
+  const long tile0 = (long)tile * PX_TILE;
+  bool ok[8];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    pix[j] = tile0 + (long)j * (256 * VEC) + tid * VEC;
-    ok[j] = pix[j] < HW;  // HW % VEC == 0 for VEC = 4, so a vector is all-in or all-out
-  }
+  for (int i = 0; i < 8; ++i) ok[i] = P::pix(tile0, tid, i) < HW;
   float pmax[8], psum[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pmax[i] = -INFINITY; psum[i] = 0.f; }
 
 #pragma unroll 1
   for (int c = 0; c < 128; ++c) {
-    const float* plane = (c < 64 ? pre_c + b * pc_img + c * HW : pre + b * p_img + (c - 64) * HW);
+    const typename P::T* plane = (c < 64 ? pre_c + b * pc_img + c * HW : pre + b * p_img + (c - 64) * HW);
     float v[8];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if constexpr (VEC == 4) {
-        float4 q = ok[j] ? *reinterpret_cast<const float4*>(plane + pix[j]) : make_float4(0, 0, 0, 0);
-        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
-      } else {
-        v[j] = ok[j] ? plane[pix[j]] : 0.f;
-      }
-    }
+    P::load(plane, tile0, tid, HW, v);
     float s = 0.f, m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool k = ok[i / VEC];
       pmax[i] = fmaxf(pmax[i], v[i]);
       psum[i] += v[i];
-      s += v[i];                       // out-of-range lanes contribute 0
-      m = k ? fmaxf(m, v[i]) : m;
+      s += v[i];                          // out-of-range pixels load as 0
+      m = ok[i] ? fmaxf(m, v[i]) : m;
     }
     s = wave_sum(s);
     m = wave_max(m);
@@ -79,18 +65,9 @@ __global__ __launch_bounds__(256) void cac_stats_kernel(const float* __restrict_
   // per-pixel outputs: plane 0 = channel max, plane 1 = channel mean (max FIRST, CAC_module.py:81)
   float* pm = pooled + (long)b * 2 * HW;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    if (!ok[j]) continue;
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(pm + pix[j]) = make_float4(pmax[4 * j], pmax[4 * j + 1], pmax[4 * j + 2], pmax[4 * j + 3]);
-      *reinterpret_cast<float4*>(pm + HW + pix[j]) =
-          make_float4(psum[4 * j] * (1.f / 128.f), psum[4 * j + 1] * (1.f / 128.f), psum[4 * j + 2] * (1.f / 128.f),
-                      psum[4 * j + 3] * (1.f / 128.f));
-    } else {
-      pm[pix[j]] = pmax[j];
-      pm[HW + pix[j]] = psum[j] * (1.f / 128.f);
-    }
-  }
+  for (int i = 0; i < 8; ++i) psum[i] *= (1.f / 128.f);
+  P::storef(pm, tile0, tid, HW, pmax);
+  P::storef(pm + HW, tile0, tid, HW, psum);
   __syncthreads();
   if (tid < 128) {
     const float s = (red[tid][0][0] + red[tid][1][0]) + (red[tid][2][0] + red[tid][3][0]);
@@ -173,33 +150,30 @@ __global__ __launch_bounds__(256) void cac_spatial_kernel(const float* __restric
   sp[(long)b * HW + (long)gy * W + gx] = 1.f / (1.f + expf(-a));
 }
 
-// out = pre * (ch*sp) + inputs  for both streams (blockIdx.z selects the stream).
+// out = pre * (ch*sp) + inputs  for both streams (blockIdx.z selects the stream).  grid = (ntiles, B*64, 2)
+template <class T>
 struct ApplyStream {
-  const float* pre; const float* in; float* out;
+  const T* pre; const T* in; T* out;
   long pre_img, in_img, out_img;  // elements per image (ctotal*HW); base pointers include coff*HW
 };
-template <int VEC>
-__global__ __launch_bounds__(256) void cac_apply_kernel(const ApplyStream sd, const ApplyStream sc,
+template <class P>
+__global__ __launch_bounds__(256) void cac_apply_kernel(const ApplyStream<typename P::T> sd,
+                                                        const ApplyStream<typename P::T> sc,
                                                         const float* __restrict__ ch, const float* __restrict__ sp,
                                                         long HW) {
   const int bc = blockIdx.y;  // b*64 + c
   const int b = bc >> 6, c = bc & 63;
-  const long pix = (blockIdx.x * 256L + threadIdx.x) * VEC;
-  if (pix >= HW) return;
-  const ApplyStream& s = blockIdx.z ? sc : sd;
-  const float* p = s.pre + b * s.pre_img + c * HW + pix;
-  const float* r = s.in + b * s.in_img + c * HW + pix;
-  float* o = s.out + b * s.out_img + c * HW + pix;
-  const float g = ch[bc];
-  if constexpr (VEC == 4) {
-    const float4 q4 = *reinterpret_cast<const float4*>(sp + (long)b * HW + pix);
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    const float4 q = *reinterpret_cast<const float4*>(r);
-    *reinterpret_cast<float4*>(o) = make_float4(fmaf(v.x, g * q4.x, q.x), fmaf(v.y, g * q4.y, q.y),
-                                                fmaf(v.z, g * q4.z, q.z), fmaf(v.w, g * q4.w, q.w));
-  } else {
-    *o = fmaf(*p, g * sp[(long)b * HW + pix], *r);
-  }
+  const int tid = threadIdx.x;
+  const long tile0 = (long)blockIdx.x * PX_TILE;
+  const ApplyStream<typename P::T>& s = blockIdx.z ? sc : sd;
+  float v[8], q[8], g[8];
+  P::load(s.pre + b * s.pre_img + c * HW, tile0, tid, HW, v);
+  P::load(s.in + b * s.in_img + c * HW, tile0, tid, HW, q);
+  P::loadf(sp + (long)b * HW, tile0, tid, HW, g);
+  const float gc = ch[bc];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], gc * g[i], q[i]);
+  P::store(s.out + b * s.out_img + c * HW, tile0, tid, HW, v);
 }
 
 static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
@@ -209,19 +183,19 @@ static bool aligned16(const void* a, const void* b = nullptr, const void* c = nu
 
 int cac_stats_tiles(int H, int W) { return (int)(((long)H * W + STATS_TILE - 1) / STATS_TILE); }
 
-int cac_stats_fwd_f32(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
-                      float* partials, hipStream_t stream) {
+int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
+                  float* partials, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
   const int nt = cac_stats_tiles(H, W);
   CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
-  const float* pre_c = (const float*)pc->data + pc->coff * HW;
-  const float* pre = (const float*)pd->data + pd->coff * HW;
-  if (HW % 4 == 0 && aligned16(pre_c, pre, pooled))
-    hipLaunchKernelGGL(cac_stats_kernel<4>, dim3(nt, B), dim3(256), 0, stream, pre_c, pc->ctotal * HW, pre,
-                       pd->ctotal * HW, pooled, partials, HW, nt);
-  else
-    hipLaunchKernelGGL(cac_stats_kernel<1>, dim3(nt, B), dim3(256), 0, stream, pre_c, pc->ctotal * HW, pre,
-                       pd->ctotal * HW, pooled, partials, HW, nt);
+  const size_t es = dtype == CODON_BF16 ? 2 : 4;
+  const char* pre_c = (const char*)pc->data + pc->coff * HW * es;
+  const char* pre = (const char*)pd->data + pd->coff * HW * es;
+  px_dispatch(dtype, HW, aligned16(pre_c, pre, pooled), [&](auto pol) {
+    using P = decltype(pol);
+    hipLaunchKernelGGL(cac_stats_kernel<P>, dim3(nt, B), dim3(256), 0, stream, (const typename P::T*)pre_c,
+                       pc->ctotal * HW, (const typename P::T*)pre, pd->ctotal * HW, pooled, partials, HW, nt);
+  });
   return check_launch("cac_stats_kernel");
 }
 
@@ -241,27 +215,28 @@ int cac_spatial_fwd(int B, int H, int W, const float* pooled, const float* w, fl
   return check_launch("cac_spatial_kernel");
 }
 
-int cac_apply_fwd_f32(int B, int H, int W, const codon_tensor* pre, const codon_tensor* pre_c, const float* ch,
-                      const float* sp, const codon_tensor* in, const codon_tensor* in_c, const codon_tensor* out,
-                      const codon_tensor* out_c, hipStream_t stream) {
+int cac_apply_fwd(int B, int H, int W, const codon_tensor* pre, const codon_tensor* pre_c, const float* ch,
+                  const float* sp, const codon_tensor* in, const codon_tensor* in_c, const codon_tensor* out,
+                  const codon_tensor* out_c, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
   CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: batch %d too large", B);
-  auto mk = [&](const codon_tensor* p, const codon_tensor* i, const codon_tensor* o) {
-    ApplyStream s;
-    s.pre = (const float*)p->data + p->coff * HW; s.pre_img = p->ctotal * HW;
-    s.in = (const float*)i->data + i->coff * HW; s.in_img = i->ctotal * HW;
-    s.out = (float*)o->data + o->coff * HW; s.out_img = o->ctotal * HW;
-    return s;
-  };
-  const ApplyStream sd = mk(pre, in, out), sc = mk(pre_c, in_c, out_c);
-  const bool v4 = HW % 4 == 0 && aligned16(sd.pre, sd.in, sd.out, sp) && aligned16(sc.pre, sc.in, sc.out);
-  if (v4) {
-    const unsigned gx = (unsigned)((HW / 4 + 255) / 256);
-    hipLaunchKernelGGL(cac_apply_kernel<4>, dim3(gx, B * 64, 2), dim3(256), 0, stream, sd, sc, ch, sp, HW);
-  } else {
-    const unsigned gx = (unsigned)((HW + 255) / 256);
-    hipLaunchKernelGGL(cac_apply_kernel<1>, dim3(gx, B * 64, 2), dim3(256), 0, stream, sd, sc, ch, sp, HW);
-  }
+  const size_t es = dtype == CODON_BF16 ? 2 : 4;
+  auto base = [&](const codon_tensor* t) { return (char*)t->data + t->coff * HW * es; };
+  const bool al = aligned16(base(pre), base(in), base(out), sp) && aligned16(base(pre_c), base(in_c), base(out_c));
+  const unsigned nt = (unsigned)((HW + PX_TILE - 1) / PX_TILE);
+  px_dispatch(dtype, HW, al, [&](auto pol) {
+    using P = decltype(pol);
+    using T = typename P::T;
+    auto mk = [&](const codon_tensor* p, const codon_tensor* i, const codon_tensor* o) {
+      ApplyStream<T> s;
+      s.pre = (const T*)base(p); s.pre_img = p->ctotal * HW;
+      s.in = (const T*)base(i); s.in_img = i->ctotal * HW;
+      s.out = (T*)base(o); s.out_img = o->ctotal * HW;
+      return s;
+    };
+    hipLaunchKernelGGL(cac_apply_kernel<P>, dim3(nt, B * 64, 2), dim3(256), 0, stream, mk(pre, in, out),
+                       mk(pre_c, in_c, out_c), ch, sp, HW);
+  });
   return check_launch("cac_apply_kernel");
 }
 

@@ -32,7 +32,7 @@ int conv2d_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, c
 size_t conv_wgrad_workspace_bytes(const codon_conv_desc*);
 int conv2d_wgrad_f32(const codon_conv_desc*, const float*, const float*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
-int stem_fwd_f32(int, int, int, const float*, const float*, float*, int, int, int, const float*, int, int, hipStream_t);
+int stem_fwd(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
 size_t conv1ch_wgrad_workspace_bytes(int, int, int);
 int conv1ch_wgrad(int, int, int, const float*, int, int, const float*, float*, int, float*, size_t, hipStream_t);
 int cac_bwd_tiles(int, int);
@@ -46,14 +46,16 @@ int cac_bwd_apply(int, int, int, const codon_tensor*, const codon_tensor*, const
                   const float*, const float*, const float*, const float*, const float*, const int*,
                   const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
 int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
-int head_fwd_f32(int, int, int, const float*, int, int, const float*, const float*, float*, hipStream_t);
+int head_fwd(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
 int cac_stats_tiles(int, int);
-int cac_stats_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, hipStream_t);
+int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t);
+int conv2d_fwd_bf16(const codon_conv_desc*, const void*, const void*, void*, const void*, hipStream_t);
+int pack_weight_bf16(const float*, void*, int, int, int, int, hipStream_t);
 int cac_gate_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
                  hipStream_t);
 int cac_spatial_fwd(int, int, int, const float*, const float*, float*, hipStream_t);
-int cac_apply_fwd_f32(int, int, int, const codon_tensor*, const codon_tensor*, const float*, const float*,
-                      const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, hipStream_t);
+int cac_apply_fwd(int, int, int, const codon_tensor*, const codon_tensor*, const float*, const float*,
+                  const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
 
 int bicubic_upsample(int, int, int, int, const float*, const float*, float*, hipStream_t);
 
@@ -84,6 +86,10 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
   const int kin = mode == CODON_PACK_DGRAD ? cout : cin;
   CODON_REQUIRE(cout > 0 && cin > 0 && kin % conv_ck(ksize) == 0, CODON_ERR_UNSUPPORTED,
                 "conv_pack_weight: cin=%d cout=%d not a multiple of the channel chunk", cin, cout);
+  if (dtype == CODON_BF16) {
+    CODON_REQUIRE(kin % 16 == 0, CODON_ERR_UNSUPPORTED, "conv_pack_weight: bf16 needs cin %% 16 == 0");
+    return pack_weight_bf16(w_oihw, w_packed, cout, cin, ksize, mode, (hipStream_t)stream);
+  }
   CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: dtype %d", dtype);
   return pack_weight_f32(w_oihw, (float*)w_packed, cout, cin, ksize, mode, (hipStream_t)stream);
 }
@@ -105,6 +111,7 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
                   "conv2d_fwd: residual slice outside its buffer");
   }
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_fwd: packed weights not 16-byte aligned");
+  if (d->dtype == CODON_BF16) return conv2d_fwd_bf16(d, x, w_packed, y, residual, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_fwd: dtype %d", d->dtype);
   return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
                         (hipStream_t)stream);
@@ -132,9 +139,9 @@ int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
   CODON_REQUIRE(x && w_oihw && y, CODON_ERR_BAD_ARG, "stem_fwd: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stem_fwd: bad shape");
   CODON_REQUIRE(y_coff >= 0 && y_coff + 64 <= y_ctotal, CODON_ERR_BAD_ARG, "stem_fwd: output slice outside buffer");
-  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
-  return stem_fwd_f32(batch, height, width, x, w_oihw, (float*)y, y_ctotal, y_coff, 1, nullptr, 0, 0,
-                      (hipStream_t)stream);
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
+  return stem_fwd(batch, height, width, x, w_oihw, y, y_ctotal, y_coff, 1, nullptr, 0, 0, dtype,
+                  (hipStream_t)stream);
 }
 
 int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal, int32_t x_coff,
@@ -142,9 +149,8 @@ int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, 
   CODON_REQUIRE(x && w_oihw && residual && y, CODON_ERR_BAD_ARG, "head_fwd: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "head_fwd: bad shape");
   CODON_REQUIRE(x_coff >= 0 && x_coff + 64 <= x_ctotal, CODON_ERR_BAD_ARG, "head_fwd: input slice outside buffer");
-  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
-  return head_fwd_f32(batch, height, width, (const float*)x, x_ctotal, x_coff, w_oihw, residual, y,
-                      (hipStream_t)stream);
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
+  return head_fwd(batch, height, width, x, x_ctotal, x_coff, w_oihw, residual, y, dtype, (hipStream_t)stream);
 }
 
 int32_t codon_cac_stats_tiles(int32_t height, int32_t width) {
@@ -159,8 +165,8 @@ int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codo
                 "cac_stats_fwd: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_stats_fwd: bad shape");
   CODON_REQUIRE(((uintptr_t)partials % 8) == 0, CODON_ERR_BAD_ARG, "cac_stats_fwd: partials not 8-byte aligned");
-  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
-  return cac_stats_fwd_f32(batch, height, width, pre_c, pre, pooled, partials, (hipStream_t)stream);
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
+  return cac_stats_fwd(batch, height, width, pre_c, pre, pooled, partials, dtype, (hipStream_t)stream);
 }
 
 int codon_cac_gate_fwd(int32_t batch, int32_t height, int32_t width, const float* partials, const float* w1,
@@ -186,9 +192,9 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
                     slice_ok(out) && slice_ok(out_c),
                 CODON_ERR_BAD_ARG, "cac_apply_fwd: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_apply_fwd: bad shape");
-  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
-  return cac_apply_fwd_f32(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c,
-                           (hipStream_t)stream);
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
+  return cac_apply_fwd(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c, dtype,
+                       (hipStream_t)stream);
 }
 
 int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_64x9,
@@ -197,10 +203,9 @@ int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const floa
   CODON_REQUIRE(x && w_64x9 && slice_ok(y) && (!mask || slice_ok(mask)), CODON_ERR_BAD_ARG,
                 "stencil_1to64: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stencil_1to64: bad shape");
-  CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "stencil_1to64: dtype %d", dtype);
-  return stem_fwd_f32(batch, height, width, x, w_64x9, (float*)y->data, y->ctotal, y->coff, flags,
-                      mask ? (const float*)mask->data : nullptr, mask ? mask->ctotal : 0, mask ? mask->coff : 0,
-                      (hipStream_t)stream);
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "stencil_1to64: dtype %d", dtype);
+  return stem_fwd(batch, height, width, x, w_64x9, y->data, y->ctotal, y->coff, flags, mask ? mask->data : nullptr,
+                  mask ? mask->ctotal : 0, mask ? mask->coff : 0, dtype, (hipStream_t)stream);
 }
 
 size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_t width) {

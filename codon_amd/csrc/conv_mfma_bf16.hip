@@ -1,0 +1,286 @@
+// bf16 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+// Same conv as conv_mfma_f32.hip (nn.Conv2d stride 1 / pad k//2 / no bias of CODON_x4.py:24-47), for
+// BASELINE.json configs[2] and [4] (bf16 activations and weights, fp32 master weights kept by the caller).
+//
+// Operand roles as in the fp32 kernel (A = weights -> cout rows, B = activations -> pixel columns), so
+// the 32x32 result again has one pixel column per lane and 16 cout rows in registers: every accumulator
+// register stores as 32 consecutive NCHW pixels of one cout plane.  What changes is K: one MFMA now
+// consumes 16 input channels, 8 consecutive ones per lane (A: W[co][8h..8h+7], B: X[8h..8h+7][pix]), so
+// both LDS images are channel-blocked:
+//   xs[cb][row][col] : 16-byte elements = 8 channels of one pixel (NHWC-within-8);  B fragment of a
+//                      half-wave = 32 consecutive elements of one tile row  -> conflict-free ds_read_b128
+//   ws[dx][cb][cout] : 16-byte elements = 8 input channels of one (tap, cout);      A fragment likewise
+// HBM stays NCHW (coalesced along W); the channel-blocking transpose happens while staging: each thread
+// loads two channels of a pixel run, packs them to 32-bit words and writes them into the blocked image.
+// The packed weight image is produced once per weight version in exactly the ws stage order.
+//
+// K loop: stages = (chunk of 16 channels, filter row dy): KS taps x 1 MFMA k-step x (2 pixel rows x COUT/32)
+// MFMAs per wave per stage; xs / ws double-buffered, next stage prefetched to registers before the MFMAs
+// and written to LDS after them, one barrier per stage (same schedule as the fp32 kernel).
+
+#include <hip/hip_bf16.h>
+
+#include "codon_common.h"
+
+namespace codon {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+struct Conv16Params {
+  const u16* x;
+  const uint4* w;  // packed: [chunk][dy][dx][cb in chunk (2)][cout] x 16 B
+  u16* y;
+  const u16* res;
+  int H, W;
+  long x_img, y_img, r_img;
+  long x_base, y_base, r_base;
+  int tiles_x, tiles_y, nblk;
+  int flags;
+};
+
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f32_to_bf16(float f) {
+  // round-to-nearest-even via the compiler's native conversion (v_cvt_pk_bf16_f32 on gfx950; keeps NaN a NaN)
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<u16*>(&b);
+}
+
+template <int KS, int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
+  constexpr int PAD = KS / 2;
+  constexpr int PSEG = 2;
+  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
+  constexpr int CK = 16, NCB = CK / 8;
+  constexpr int NCHUNK = CIN / CK;
+  constexpr int XS = NCB * XR * XQ;   // 16-byte elements per input buffer
+  constexpr int WS = KS * NCB * COUT; // 16-byte elements per weight stage
+  constexpr int CT = COUT / 32;
+  constexpr int NST = NCHUNK * KS;
+  constexpr int XW = (CK / 2) * XR * XQ;  // 32-bit words (channel pairs) per input tile
+  constexpr int XE = (XW + 255) / 256;
+  constexpr int WE = (WS + 255) / 256;
+
+  __shared__ uint4 lds[2 * XS + 2 * WS];
+  uint4* const xs0 = lds;
+  uint4* const ws0 = lds + 2 * XS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int tx0 = tx * TW, ty0 = ty * TH;
+  const int H = p.H, W = p.W;
+  const long HW = (long)H * W;
+
+  const u16* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
+  const uint4* __restrict__ wg = p.w;
+
+  // gather plan: word e = (channel pair cp, row r, col q), q fastest (coalesced along W)
+  int xoff[XE];
+  int xdst[XE];
+  unsigned xmask = 0;
+#pragma unroll
+  for (int k = 0; k < XE; ++k) {
+    const int e = tid + k * 256;
+    const int cp = e / (XR * XQ);
+    const int rem = e - cp * (XR * XQ);
+    const int r = rem / XQ, q = rem - r * XQ;
+    const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+    const bool ok = (e < XW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    xoff[k] = ok ? (int)((2 * cp) * HW + (long)gy * W + gx) : 0;
+    xmask |= ok ? (1u << k) : 0u;
+    // destination 32-bit word index inside the blocked image: element ((cp/4)*XR + r)*XQ + q, word cp%4
+    xdst[k] = (((cp >> 2) * XR + r) * XQ + q) * 4 + (cp & 3);
+  }
+
+  unsigned xr[XE];
+  uint4 wr[WE];
+
+#define LOAD_X(chunk_)                                                                  \
+  {                                                                                     \
+    const u16* src_ = xg + (long)(chunk_) * CK * HW;                                    \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                    \
+      const bool m_ = (xmask >> k) & 1u;                                                \
+      const unsigned lo_ = m_ ? src_[xoff[k]] : 0u;                                     \
+      const unsigned hi_ = m_ ? src_[xoff[k] + HW] : 0u;                                \
+      xr[k] = lo_ | (hi_ << 16);                                                        \
+    }                                                                                   \
+  }
+#define STORE_X(buf_)                                                                   \
+  {                                                                                     \
+    unsigned* dst_ = reinterpret_cast<unsigned*>(xs0 + (buf_) * XS);                    \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k)                                      \
+        if (XW % 256 == 0 || tid + k * 256 < XW) dst_[xdst[k]] = xr[k];                 \
+  }
+#define LOAD_W(stage_)                                                                  \
+  {                                                                                     \
+    const uint4* src_ = wg + (long)(stage_) * WS;                                       \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
+        wr[k] = (WS % 256 == 0 || tid + k * 256 < WS) ? src_[tid + k * 256]             \
+                                                      : make_uint4(0, 0, 0, 0);         \
+  }
+#define STORE_W(buf_)                                                                   \
+  {                                                                                     \
+    uint4* dst_ = ws0 + (buf_) * WS;                                                    \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
+        if (WS % 256 == 0 || tid + k * 256 < WS) dst_[tid + k * 256] = wr[k];           \
+  }
+
+  f32x16 acc[PSEG][CT];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  LOAD_X(0);
+  LOAD_W(0);
+  STORE_X(0);
+  STORE_W(0);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < NST; ++s) {
+    const int chunk = s / KS;
+    const int dy = s - chunk * KS;
+    const bool has_next = (s + 1 < NST);
+    const bool next_chunk = has_next && (dy == KS - 1);
+    if (has_next) LOAD_W(s + 1);
+    if (next_chunk) LOAD_X(chunk + 1);
+
+    const uint4* xb = xs0 + (chunk & 1) * XS + (half * XR + wave * PSEG + dy) * XQ + l31;
+    const uint4* wb = ws0 + (s & 1) * WS + half * COUT + l31;
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      bf16x8 a[CT], bv[PSEG];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const uint4 v = wb[dx * NCB * COUT + t * 32];
+        a[t] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const uint4 v = xb[i * XQ + dx];
+        bv[i] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], bv[i], acc[i][t], 0, 0, 0);
+    }
+
+    if (has_next) STORE_W((s + 1) & 1);
+    if (next_chunk) STORE_X((chunk + 1) & 1);
+    __syncthreads();
+  }
+#undef LOAD_X
+#undef STORE_X
+#undef LOAD_W
+#undef STORE_W
+
+  const int gx = tx0 + l31;
+  if (gx < W) {
+    u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
+    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    const bool relu = p.flags & CODON_CONV_RELU;
+    const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
+    const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) {
+      const int gy = ty0 + wave * PSEG + i;
+      if (gy < H) {
+        const long pix = (long)gy * W + gx;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][t][r];
+            if (relu) v = fmaxf(v, 0.f);
+            if (addr) v += bf16_to_f32(rg[co * HW + pix]);
+            if (mask) v = bf16_to_f32(rg[co * HW + pix]) > 0.f ? v : 0.f;
+            if (accum) v += bf16_to_f32(yg[co * HW + pix]);
+            yg[co * HW + pix] = f32_to_bf16(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> bf16 packed [chunk][dy][dx][cb (2)][cout][8 ch]; DGRAD: flipped taps, in/out swapped.
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks,
+                                        int dgrad) {
+  const int kin = dgrad ? cout : cin, kout = dgrad ? cin : cout;
+  const long n = (long)kin * kout * ks * ks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int j = t % 8; t /= 8;
+    const int o = t % kout; t /= kout;
+    const int cb = t % 2; t /= 2;
+    const int dx = t % ks; t /= ks;
+    const int dy = t % ks; t /= ks;
+    const int chunk = (int)t;
+    const int ci = chunk * 16 + cb * 8 + j;
+    float v;
+    if (!dgrad) v = w[(((long)o * cin + ci) * ks + dy) * ks + dx];
+    else v = w[(((long)ci * cin + o) * ks + (ks - 1 - dy)) * ks + (ks - 1 - dx)];
+    out[i] = f32_to_bf16(v);
+  }
+}
+
+template <int KS, int CIN, int COUT>
+static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                         hipStream_t stream) {
+  Conv16Params p;
+  p.x = (const u16*)x; p.w = (const uint4*)w; p.y = (u16*)y; p.res = (const u16*)res;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = d->r_ctotal * HW;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + 7) / 8;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_mfma_bf16_kernel");
+}
+
+int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                    hipStream_t stream) {
+  const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
+  switch (key) {
+    case 5128128: return launch_conv16<5, 128, 128>(d, x, w, y, res, stream);
+    case 5064064: return launch_conv16<5, 64, 64>(d, x, w, y, res, stream);
+    case 3064064: return launch_conv16<3, 64, 64>(d, x, w, y, res, stream);
+    case 3128064: return launch_conv16<3, 128, 64>(d, x, w, y, res, stream);
+    case 3064128: return launch_conv16<3, 64, 128>(d, x, w, y, res, stream);
+    case 1128064: return launch_conv16<1, 128, 64>(d, x, w, y, res, stream);
+    case 1064128: return launch_conv16<1, 64, 128>(d, x, w, y, res, stream);
+    default:
+      set_error("conv2d_fwd: no bf16 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      return CODON_ERR_UNSUPPORTED;
+  }
+}
+
+int pack_weight_bf16(const float* w, void* out, int cout, int cin, int ks, int mode, hipStream_t stream) {
+  const long n = (long)cout * cin * ks * ks;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks,
+                     mode == CODON_PACK_DGRAD ? 1 : 0);
+  return check_launch("pack_weight_bf16_kernel");
+}
+
+}  // namespace codon

@@ -6,6 +6,7 @@
 // plane row is then 16-byte aligned); other widths take the VEC=1 instantiation.
 
 #include "codon_common.h"
+#include "px8.h"
 
 namespace codon {
 
@@ -16,8 +17,32 @@ struct Vec<4> { using T = float4; };
 template <>
 struct Vec<1> { using T = float; };
 
-template <int VEC>
-__device__ __forceinline__ void load_row(const float* __restrict__ plane, int gy, int gx0, int H, int W,
+// element accessors: T = float (fp32 activations) or u16_t (bf16 activations); math is always fp32
+__device__ __forceinline__ float ldx(const float* p) { return *p; }
+__device__ __forceinline__ float ldx(const u16_t* p) { return b2f(*p); }
+__device__ __forceinline__ void stx(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stx(u16_t* p, float v) { *p = f2b(v); }
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+  const float4 c = *reinterpret_cast<const float4*>(p);
+  o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+}
+__device__ __forceinline__ void ld4(const u16_t* p, float (&o)[4]) {
+  const uint2 c = *reinterpret_cast<const uint2*>(p);
+  o[0] = __uint_as_float(c.x << 16); o[1] = __uint_as_float(c.x & 0xffff0000u);
+  o[2] = __uint_as_float(c.y << 16); o[3] = __uint_as_float(c.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void st4(u16_t* p, const float (&o)[4]) {
+  uint2 c;
+  c.x = (unsigned)f2b(o[0]) | ((unsigned)f2b(o[1]) << 16);
+  c.y = (unsigned)f2b(o[2]) | ((unsigned)f2b(o[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = c;
+}
+
+template <int VEC, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ plane, int gy, int gx0, int H, int W,
                                          float (&v)[VEC + 2]) {
   // v[0] = pixel gx0-1 ... v[VEC+1] = pixel gx0+VEC, zero outside the image
   if (gy < 0 || gy >= H) {
@@ -25,25 +50,26 @@ __device__ __forceinline__ void load_row(const float* __restrict__ plane, int gy
     for (int i = 0; i < VEC + 2; ++i) v[i] = 0.f;
     return;
   }
-  const float* row = plane + (long)gy * W;
+  const T* row = plane + (long)gy * W;
   if constexpr (VEC == 4) {
-    const float4 c = *reinterpret_cast<const float4*>(row + gx0);
-    v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
+    float c[4];
+    ld4(row + gx0, c);
+    v[1] = c[0]; v[2] = c[1]; v[3] = c[2]; v[4] = c[3];
   } else {
-    v[1] = row[gx0];
+    v[1] = ldx(row + gx0);
   }
-  v[0] = gx0 > 0 ? row[gx0 - 1] : 0.f;
-  v[VEC + 1] = gx0 + VEC < W ? row[gx0 + VEC] : 0.f;
+  v[0] = gx0 > 0 ? ldx(row + gx0 - 1) : 0.f;
+  v[VEC + 1] = gx0 + VEC < W ? ldx(row + gx0 + VEC) : 0.f;
 }
 
 // flags: 1 = ReLU on the output; 2 = use the spatially flipped taps (w[c][8-t]): with w = output.weight
 // this is dL/dt of the head conv (y = sum_c conv3x3(t_c, w_c)) given dL/dy.
 // mask (optional, 64 channels): out = mask > 0 ? out : 0 (backward through conv11's ReLU).
-template <int VEC>
+template <int VEC, typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   float* __restrict__ y, int H, int W, long y_img,
+                                                   T* __restrict__ y, int H, int W, long y_img,
                                                    long y_base, long total, int flags,
-                                                   const float* __restrict__ mask, long m_img, long m_base) {
+                                                   const T* __restrict__ mask, long m_img, long m_base) {
   __shared__ float wsh[64 * 9];
   for (int i = threadIdx.x; i < 576; i += 256) wsh[i] = (flags & 2) ? w[(i / 9) * 9 + 8 - (i % 9)] : w[i];
   __syncthreads();
@@ -57,12 +83,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   const int gx0 = gxv * VEC;
   const float* plane = x + (long)b * H * W;
   float r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
-  load_row<VEC>(plane, gy - 1, gx0, H, W, r0);
-  load_row<VEC>(plane, gy, gx0, H, W, r1);
-  load_row<VEC>(plane, gy + 1, gx0, H, W, r2);
+  load_row<VEC, float>(plane, gy - 1, gx0, H, W, r0);
+  load_row<VEC, float>(plane, gy, gx0, H, W, r1);
+  load_row<VEC, float>(plane, gy + 1, gx0, H, W, r2);
   const long HW = (long)H * W;
-  float* yo = y + (long)b * y_img + y_base + (long)gy * W + gx0;
-  const float* mo = mask ? mask + (long)b * m_img + m_base + (long)gy * W + gx0 : nullptr;
+  T* yo = y + (long)b * y_img + y_base + (long)gy * W + gx0;
+  const T* mo = mask ? mask + (long)b * m_img + m_base + (long)gy * W + gx0 : nullptr;
   const bool relu = flags & 1;
 #pragma unroll 4
   for (int co = 0; co < 64; ++co) {
@@ -83,20 +109,21 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     }
     if (mo) {
       if constexpr (VEC == 4) {
-        const float4 m = *reinterpret_cast<const float4*>(mo + co * HW);
-        o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
-        o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+        float m[4];
+        ld4(mo + co * HW, m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = m[i] > 0.f ? o[i] : 0.f;
       } else {
-        o[0] = mo[co * HW] > 0.f ? o[0] : 0.f;
+        o[0] = ldx(mo + co * HW) > 0.f ? o[0] : 0.f;
       }
     }
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(yo + co * HW) = make_float4(o[0], o[1], o[2], o[3]);
-    else yo[co * HW] = o[0];
+    if constexpr (VEC == 4) st4(yo + co * HW, o);
+    else stx(yo + co * HW, o[0]);
   }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ res, float* __restrict__ y, int H,
                                                    int W, long x_img, long x_base, long total) {
   __shared__ float wsh[64 * 9];
@@ -111,18 +138,18 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   const int b = (int)(t / H);
   const int gx0 = gxv * VEC;
   const long HW = (long)H * W;
-  const float* xb = x + (long)b * x_img + x_base;
+  const T* xb = x + (long)b * x_img + x_base;
   float o[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) o[i] = 0.f;
 #pragma unroll 2
   for (int c = 0; c < 64; ++c) {
-    const float* plane = xb + c * HW;
+    const T* plane = xb + c * HW;
     const float* k = wsh + c * 9;
     float r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
-    load_row<VEC>(plane, gy - 1, gx0, H, W, r0);
-    load_row<VEC>(plane, gy, gx0, H, W, r1);
-    load_row<VEC>(plane, gy + 1, gx0, H, W, r2);
+    load_row<VEC, T>(plane, gy - 1, gx0, H, W, r0);
+    load_row<VEC, T>(plane, gy, gx0, H, W, r1);
+    load_row<VEC, T>(plane, gy + 1, gx0, H, W, r2);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float a = o[i];
@@ -147,8 +174,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   }
 }
 
-int stem_fwd_f32(int B, int H, int W, const float* x, const float* w, float* y, int y_ctotal, int y_coff,
-                 int flags, const float* mask, int m_ctotal, int m_coff, hipStream_t stream) {
+template <typename T>
+static int stem_launch(int B, int H, int W, const float* x, const float* w, T* y, int y_ctotal, int y_coff, int flags,
+                       const T* mask, int m_ctotal, int m_coff, hipStream_t stream) {
   const long HW = (long)H * W;
   const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                                     reinterpret_cast<uintptr_t>(mask)) % 16 == 0);
@@ -156,16 +184,26 @@ int stem_fwd_f32(int B, int H, int W, const float* x, const float* w, float* y, 
   const long blocks = (total + 255) / 256;
   CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "stem_fwd: grid too large");
   if (v4)
-    hipLaunchKernelGGL(stem_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W, y_ctotal * HW,
-                       y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
+    hipLaunchKernelGGL((stem_kernel<4, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W,
+                       y_ctotal * HW, y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
   else
-    hipLaunchKernelGGL(stem_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W, y_ctotal * HW,
-                       y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
+    hipLaunchKernelGGL((stem_kernel<1, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, y, H, W,
+                       y_ctotal * HW, y_coff * HW, total, flags, mask, m_ctotal * HW, m_coff * HW);
   return check_launch("stem_kernel");
 }
 
-int head_fwd_f32(int B, int H, int W, const float* x, int x_ctotal, int x_coff, const float* w, const float* res,
-                 float* y, hipStream_t stream) {
+int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y_ctotal, int y_coff, int flags,
+             const void* mask, int m_ctotal, int m_coff, int dtype, hipStream_t stream) {
+  if (dtype == CODON_BF16)
+    return stem_launch<u16_t>(B, H, W, x, w, (u16_t*)y, y_ctotal, y_coff, flags, (const u16_t*)mask, m_ctotal, m_coff,
+                              stream);
+  return stem_launch<float>(B, H, W, x, w, (float*)y, y_ctotal, y_coff, flags, (const float*)mask, m_ctotal, m_coff,
+                            stream);
+}
+
+template <typename T>
+static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff, const float* w, const float* res,
+                       float* y, hipStream_t stream) {
   const long HW = (long)H * W;
   const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                                     reinterpret_cast<uintptr_t>(res)) % 16 == 0);
@@ -173,12 +211,18 @@ int head_fwd_f32(int B, int H, int W, const float* x, int x_ctotal, int x_coff, 
   const long blocks = (total + 255) / 256;
   CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "head_fwd: grid too large");
   if (v4)
-    hipLaunchKernelGGL(head_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
+    hipLaunchKernelGGL((head_kernel<4, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
                        x_ctotal * HW, x_coff * HW, total);
   else
-    hipLaunchKernelGGL(head_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
+    hipLaunchKernelGGL((head_kernel<1, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
                        x_ctotal * HW, x_coff * HW, total);
   return check_launch("head_kernel");
+}
+
+int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
+             int dtype, hipStream_t stream) {
+  if (dtype == CODON_BF16) return head_launch<u16_t>(B, H, W, (const u16_t*)x, x_ctotal, x_coff, w, res, y, stream);
+  return head_launch<float>(B, H, W, (const float*)x, x_ctotal, x_coff, w, res, y, stream);
 }
 
 // ---- weight gradient of the 1->64 / 64->1 3x3 convs ----------------------------------------------

@@ -114,16 +114,34 @@ class _CODONBase(nn.Module):
             self.attention_c5 = ChannelGate(64)
             self.attention_s5 = CAC_spatial()
         self._pack_cache: Dict[str, tuple] = {}
+        self.compute_dtype: Optional[torch.dtype] = None
+
+    def set_compute_dtype(self, dtype: Optional[torch.dtype]):
+        """Activation / MFMA operand dtype: None = follow the parameters' dtype; torch.bfloat16 with fp32
+        parameters = bf16 activations and packed weights, fp32 accumulate, fp32 master weights
+        (BASELINE.json configs[2], [4]).  Inputs and the output stay fp32 1-channel maps."""
+        if dtype not in (None, torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"codon_amd.CODONNet: compute dtype {dtype} not supported (fp32, bf16)")
+        self.compute_dtype = dtype
+        return self
+
+    def _act_dtype(self) -> torch.dtype:
+        dt = self.compute_dtype or self.input.weight.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"codon_amd.CODONNet: dtype {dt} not supported (fp32 and bf16 only; the "
+                                      "reference's .half() inference has no kernel here and there is no fallback)")
+        return dt
 
     # -- packed weights -------------------------------------------------------------------
     def _packed(self, name: str, mode: int = L.PACK_FWD) -> torch.Tensor:
         w = getattr(self, name).weight
-        key = (name, mode)
+        adt = self._act_dtype()
+        key = (name, mode, adt)
         tag = (w.data_ptr(), w._version, w.device, w.dtype)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
-        packed = ops.packed_weight(w.detach(), mode, torch.float32)
+        packed = ops.packed_weight(w.detach(), mode, adt)
         self._pack_cache[key] = (tag, packed)
         return packed
 
@@ -144,30 +162,37 @@ class _CODONBase(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("codon_amd.CODONNet runs on MI355X only: move the module and inputs to 'cuda' "
                                "(there is no CPU fallback)")
-        if x.dtype != torch.float32 or self.input.weight.dtype != torch.float32:
-            raise NotImplementedError(f"codon_amd.CODONNet: dtype {x.dtype} not supported yet (fp32 only)")
+        adt = self._act_dtype()
+        if x.dtype not in (torch.float32, torch.bfloat16) or y.dtype != x.dtype:
+            raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16)")
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
+            if adt != torch.float32:
+                raise NotImplementedError("codon_amd.CODONNet: the bf16 backward kernels are not built yet; "
+                                          "train in fp32 or run bf16 under torch.no_grad()")
             from .autograd import codon_apply  # training path (custom backward)
             return codon_apply(self, x, y)
-        return self._forward_impl(x.contiguous(), y.contiguous(), None)
+        out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)
+        return out if x.dtype == torch.float32 else out.to(x.dtype)
 
     def _forward_impl(self, x, y, save: Optional[dict]):
         """Kernel schedule of CODONNet.forward.  With `save` (a dict) every activation the
         backward needs is kept in fresh buffers; without it buffers are reused across blocks."""
         B, _, H, W = x.shape
         dev = x.device
-        new = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
+        adt = self._act_dtype()
+        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
         P = self._packed
         keep = save is not None
+        f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
         in2 = new(128)
         t64 = new(64)
-        ops.stem(x, self.input.weight, Slice(t64))
+        ops.stem(x, f32(self.input.weight), Slice(t64))
         ops.conv2d(Slice(t64), P("conv_input"), Slice(in2, 0, 64), 3, relu=True)
         t64c = new(64) if keep else t64
-        ops.stem(y, self.input_c.weight, Slice(t64c))
+        ops.stem(y, f32(self.input_c.weight), Slice(t64c))
         ops.conv2d(Slice(t64c), P("conv_input_c"), Slice(in2, 64, 64), 3, relu=True)
         inputs, inputs_c = Slice(in2, 0, 64), Slice(in2, 64, 64)
         if keep:
@@ -201,9 +226,9 @@ class _CODONBase(nn.Module):
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
             ops.cac_stats(pre_c, pre, pooled, partials)
-            ops.cac_gate(B, H, W, partials, ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight, ac.mlp[3].bias,
-                         ch, pools)
-            ops.cac_spatial(pooled, asp.spatial.conv.weight, sp)
+            ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                         f32(ac.mlp[3].bias), ch, pools)
+            ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
             if keep or oc is None:
                 oc = new(128)           # [out | out_c]: also conv7's cat(out, out_c) input  :119
             ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
@@ -234,7 +259,7 @@ class _CODONBase(nn.Module):
         t = new(64) if keep else t64
         ops.conv2d(Slice(f), P("conv11"), Slice(t), 3, relu=True)
         outp = torch.empty_like(x)
-        ops.head(Slice(t), self.output.weight, x, outp)
+        ops.head(Slice(t), f32(self.output.weight), x, outp)
         if keep:
             save["f_last"], save["t11"] = f, t
         return outp

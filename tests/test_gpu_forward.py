@@ -106,3 +106,34 @@ def test_full_size_properties():
     m0 = _model("x4", sd0)
     with torch.no_grad():
         assert torch.equal(m0(x, y), x)
+
+
+# ---- bf16 compute (fp32 master weights): rel-RMSE <= 3e-2 vs the fp32 oracle (the reference's
+# own bf16 CPU run sits at 1.8e-2) -------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["he0_x4_2x24x20_taps", "kat0_x4_2x32x24", "he0_x16_1x33x9"])
+def test_forward_bf16_matches_golden(name):
+    z, variant, sd, x, y = load_case(name)
+    m = _model(variant, sd).set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        o = m(x.cuda(), y.cuda())
+    assert o.dtype == torch.float32
+    assert rel_rmse(o.cpu(), z["out_fp64"]) <= 3e-2
+    # .bfloat16() modules + bf16 inputs (the reference-style whole-module cast) take the same path
+    mb = _model(variant, sd).bfloat16()
+    with torch.no_grad():
+        ob = mb(x.cuda().bfloat16(), y.cuda().bfloat16())
+    assert ob.dtype == torch.bfloat16
+    assert rel_rmse(ob.float().cpu(), z["out_fp64"]) <= 4e-2
+
+
+def test_forward_bf16_random_128():
+    sd = orc.he_state("x4", seed=13)
+    g = np.random.default_rng(3)
+    x = torch.from_numpy(g.uniform(0, 1, size=(1, 1, 128, 128)).astype(np.float32))
+    y = torch.from_numpy((g.integers(0, 256, size=(1, 1, 128, 128)) / 255.0).astype(np.float32))
+    with torch.no_grad():
+        ref = orc.forward(sd, x, y)
+    m = _model("x4", sd).set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        o = m(x.cuda(), y.cuda())
+    assert rel_rmse(o.cpu(), ref) <= 3e-2

@@ -221,3 +221,69 @@ def test_conv2d_relu_mask_and_accumulate():
     ops.conv2d(Slice(gy.to(dev)), ops.packed_weight(w.to(dev), L.PACK_DGRAD), Slice(out), 3,
                relu_mask=Slice(xs.to(dev)), accumulate=True)
     assert rel_rmse(out.cpu(), base + ref) < 2e-6
+
+
+# ---- bf16 path (BASELINE configs[2], [4]): bf16 activations / weights, fp32 accumulate --------------
+
+BF16_TOL = 1e-2   # rel-RMSE of one bf16 conv vs the fp32 op on bf16-rounded operands is ~3e-3 (output rounding)
+
+
+@pytest.mark.parametrize("k,cin,cout", CONV_CASES)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 8, 32), (1, 1, 1), (1, 33, 70)])
+def test_conv2d_bf16_vs_torch(k, cin, cout, shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, cin, H, W), 1).bfloat16()
+    w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5)
+    ref = F.conv2d(x.float(), w.bfloat16().float(), None, 1, k // 2)     # same operand rounding, fp32 accumulate
+    wp = ops.packed_weight(w.to(dev), dtype=torch.bfloat16)
+    y = torch.full((B, cout, H, W), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k)
+    assert rel_rmse(y.float().cpu(), ref) < 3e-3            # only the output rounding to bf16 differs
+    r = _rand((B, cout, H, W), 3).bfloat16()
+    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, relu=True)
+    assert rel_rmse(y.float().cpu(), F.relu(ref)) < 3e-3
+    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, residual=Slice(r.to(dev)))
+    assert rel_rmse(y.float().cpu(), ref + r.float()) < 3e-3
+
+
+def test_bf16_elementwise_kernels():
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    from oracle import codon_oracle as orc
+    dev = _dev()
+    for (B, H, W) in [(2, 16, 24), (1, 19, 45), (1, 1, 1)]:
+        x = _rand((B, 1, H, W), 1)
+        w = _rand((64, 1, 3, 3), 2, 0.3)
+        y = torch.empty((B, 64, H, W), device=dev, dtype=torch.bfloat16)
+        ops.stem(x.to(dev), w.to(dev), Slice(y))
+        assert rel_rmse(y.float().cpu(), F.relu(F.conv2d(x, w, None, 1, 1))) < 3e-3
+        f = _rand((B, 64, H, W), 3).bfloat16()
+        wo = _rand((1, 64, 3, 3), 4, 0.1)
+        o = torch.empty((B, 1, H, W), device=dev)
+        ops.head(Slice(f.to(dev)), wo.to(dev), x.to(dev), o)
+        assert rel_rmse(o.cpu(), F.conv2d(f.float(), wo, None, 1, 1) + x) < 1e-5
+        pre2 = _rand((B, 128, H, W), 5).bfloat16()
+        in2 = _rand((B, 128, H, W), 6).bfloat16()
+        w1, b1, w2, b2 = _rand((8, 128), 7, 0.1), _rand((8,), 8, 0.1), _rand((64, 8), 9, 0.3), _rand((64,), 10, 0.1)
+        ws = _rand((1, 2, 5, 5), 11, 0.2)
+        pre, pre_c = pre2[:, :64].float(), pre2[:, 64:].float()
+        Fcat = torch.cat((pre_c, pre), 1)
+        ch_ref, sp_ref = orc.cac_channel(Fcat, w1, b1, w2, b2), orc.cac_spatial(Fcat, ws)
+        g = ch_ref[:, :, None, None] * sp_ref
+        p2, i2 = pre2.to(dev), in2.to(dev)
+        nt = ops.cac_stats_tiles(H, W)
+        pooled = torch.empty((B, 2, H, W), device=dev); partials = torch.empty((B, nt, 128, 2), device=dev)
+        ch = torch.empty((B, 64), device=dev); sp = torch.empty((B, 1, H, W), device=dev)
+        ops.cac_stats(Slice(p2, 64, 64), Slice(p2, 0, 64), pooled, partials)
+        assert torch.equal(pooled[:, 0].cpu(), Fcat.max(1)[0])
+        ops.cac_gate(B, H, W, partials, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), ch, None)
+        ops.cac_spatial(pooled, ws.to(dev), sp)
+        assert rmse(ch.cpu(), ch_ref) < 1e-6 and rmse(sp.cpu(), sp_ref) < 1e-6
+        oc = torch.empty((B, 128, H, W), device=dev, dtype=torch.bfloat16)
+        ops.cac_apply(Slice(p2, 0, 64), Slice(p2, 64, 64), ch, sp, Slice(i2, 0, 64), Slice(i2, 64, 64),
+                      Slice(oc, 0, 64), Slice(oc, 64, 64))
+        assert rel_rmse(oc[:, :64].float().cpu(), pre * g + in2[:, :64].float()) < 3e-3
+        assert rel_rmse(oc[:, 64:].float().cpu(), pre_c * g + in2[:, 64:].float()) < 3e-3
