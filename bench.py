@@ -130,13 +130,16 @@ def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
         step_s = dt / a.steps
         res = {"metric": "iters/sec (fwd+bwd)", "value": a.steps / dt, "unit": "it/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"CODON x{a.scale} forward+backward (L1 loss, Adam), batch {B}/GPU at {H}x{W}, fp32",
+               "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"CODON x{a.scale} forward+backward (L1 loss, Adam), batch {B}/GPU at {H}x{W}, "
+                                      f"{a.dtype}" + (" activations/gradients, fp32 accumulate + master weights "
+                                                      "(BASELINE.json configs[2] per-GPU shape)" if a.dtype == "bf16" else ""),
                           "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
                           "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
                "images_per_s": world * B * a.steps / dt,
                "whole_step": {"tflops": 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12,
-                              "frac_f32_mfma_peak": 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                              "frac_mfma_peak": 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12 /
+                              (PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS)},
                "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
         print(json.dumps(res), flush=True)
     if dist is not None:

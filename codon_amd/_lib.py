@@ -52,15 +52,15 @@ SIGNATURES = {
     "codon_cac_spatial_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "codon_stencil_1to64": (C.c_int, [_I, _I, _I, _P, _P, _TP, _I, _TP, _I, _P]),
     "codon_conv1ch_wgrad_workspace_bytes": (_S, [_I, _I, _I]),
-    "codon_conv1ch_wgrad": (C.c_int, [_I, _I, _I, _TP, _P, _P, _I, _P, _S, _P]),
-    "codon_ew_add_mask": (C.c_int, [_I, _I, _I, _I, _TP, _TP, _TP, _I, _P]),
+    "codon_conv1ch_wgrad": (C.c_int, [_I, _I, _I, _TP, _P, _P, _I, _P, _S, _I, _P]),
+    "codon_ew_add_mask": (C.c_int, [_I, _I, _I, _I, _TP, _TP, _TP, _I, _I, _P]),
     "codon_cac_bwd_tiles": (_I, [_I, _I]),
     "codon_cac_bwd_spatial_blocks": (_I, [_I, _I, _I]),
-    "codon_cac_bwd_reduce": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_bwd_reduce": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _I, _P]),
     "codon_cac_bwd_gate": (C.c_int, [_I, _I, _I] + [_P] * 14 + [_P]),
     "codon_cac_bwd_spatial": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "codon_cac_bwd_apply": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _TP, _TP, _TP, _TP,
-                                      _I, _P]),
+                                      _I, _I, _P]),
     "codon_bicubic_upsample": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
 }

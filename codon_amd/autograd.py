@@ -41,9 +41,10 @@ class _CodonFn(torch.autograd.Function):
     def forward(ctx, model, x, y, *params):
         save = {}
         with torch.no_grad():
-            out = model._forward_impl(x.contiguous(), y.contiguous(), save)
-        ctx.model, ctx.saved, ctx.x, ctx.y = model, save, x, y
-        return out
+            xf, yf = x.float().contiguous(), y.float().contiguous()
+            out = model._forward_impl(xf, yf, save)
+        ctx.model, ctx.saved, ctx.x, ctx.y = model, save, xf, yf
+        return out if x.dtype == torch.float32 else out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, g_out):
@@ -51,8 +52,7 @@ class _CodonFn(torch.autograd.Function):
         with torch.no_grad():
             grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous())
         ctx.saved = None
-        names = [n for n, _ in used_parameters(model)]
-        return (None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None) + tuple(grads[n].to(p.dtype) for n, p in used_parameters(model))
 
 
 def codon_apply(model, x, y):
@@ -63,8 +63,11 @@ def codon_apply(model, x, y):
 def _backward_impl(model, S, x, y, gy, debug=None):
     B, _, H, W = x.shape
     dev = x.device
-    new = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
-    G = {}
+    adt = model._act_dtype()                       # activation-gradient dtype follows the activations
+    new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
+    f32 = lambda t: t if t.dtype == torch.float32 else t.float()
+    gy = f32(gy)
+    G = {}                                         # parameter gradients: always fp32
 
     def Pd(name):
         return model._packed(name, L.PACK_DGRAD)
@@ -74,14 +77,14 @@ def _backward_impl(model, S, x, y, gy, debug=None):
         if key in G:
             ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=True)
         else:
-            G[key] = torch.empty_like(getattr(model, name).weight)
+            G[key] = torch.empty_like(getattr(model, name).weight, dtype=torch.float32)
             ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=False)
 
     # ---- tail: y_hat = output(t11) + x ; t11 = relu(conv11(f3))                       :129-131
     t11, f_last = S["t11"], S["f_last"]
     g_t = new(64)
-    ops.stencil_1to64(gy, model.output.weight, Slice(g_t), flip=True, mask=Slice(t11))
-    G["output.weight"] = torch.empty_like(model.output.weight)
+    ops.stencil_1to64(gy, f32(model.output.weight), Slice(g_t), flip=True, mask=Slice(t11))
+    G["output.weight"] = torch.empty_like(model.output.weight, dtype=torch.float32)
     ops.conv1ch_wgrad(Slice(t11), gy, G["output.weight"], flip=True)
     wgrad("conv11", Slice(f_last), Slice(g_t), 3)
     g_f = new(64)                                   # dL/df_3 (no ReLU on f)
@@ -129,7 +132,8 @@ def _backward_impl(model, S, x, y, gy, debug=None):
             debug[f"g_oc{i}"] = g_oc.clone()
         dw1, db1, dw2, db2, dws = ops.cac_backward(
             Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
-            Bk["pooled"], Bk["pools"], ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight, asp.spatial.conv.weight,
+            Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+            f32(asp.spatial.conv.weight),
             Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
             accumulate_in=(i != 4))
         G[f"attention_c{i}.mlp.1.weight"], G[f"attention_c{i}.mlp.1.bias"] = dw1, db1
@@ -167,6 +171,6 @@ def _backward_impl(model, S, x, y, gy, debug=None):
                                        ("input_c", "conv_input_c", S["stem_c"], y, 64)):
         wgrad(nm_ci, Slice(st), Slice(g_in2, off, 64), 3)
         ops.conv2d(Slice(g_in2, off, 64), Pd(nm_ci), Slice(g_s), 3, relu_mask=Slice(st))
-        G[nm_in + ".weight"] = torch.empty_like(getattr(model, nm_in).weight)
+        G[nm_in + ".weight"] = torch.empty_like(getattr(model, nm_in).weight, dtype=torch.float32)
         ops.conv1ch_wgrad(Slice(g_s), img, G[nm_in + ".weight"], flip=False)
     return G

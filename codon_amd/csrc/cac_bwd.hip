@@ -22,10 +22,11 @@
 #include <math.h>
 
 #include "codon_common.h"
+#include "px8.h"
 
 namespace codon {
 
-constexpr int BWD_TILE = 2048;  // pixels per workgroup, 8 per thread (same tiling as cac_stats)
+constexpr int BWD_TILE = PX_TILE;  // pixels per workgroup, 8 per thread (same tiling as cac_stats)
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -38,32 +39,21 @@ __device__ __forceinline__ int wmin(int v) {
   return v;
 }
 
+template <class T>
 struct Sl {  // 64-channel slice: base pointer already offset by coff*HW; img = ctotal*HW
-  const float* p;
+  const T* p;
   long img;
 };
+template <class T>
 struct SlW {
-  float* p;
+  T* p;
   long img;
 };
-
-template <int VEC>
-__device__ __forceinline__ void load8(const float* plane, const long (&pix)[8 / VEC], const bool (&ok)[8 / VEC],
-                                      float (&v)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8 / VEC; ++j) {
-    if constexpr (VEC == 4) {
-      const float4 q = ok[j] ? *reinterpret_cast<const float4*>(plane + pix[j]) : make_float4(0, 0, 0, 0);
-      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
-    } else {
-      v[j] = ok[j] ? plane[pix[j]] : 0.f;
-    }
-  }
-}
 
 // ---- A -------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl g_out, Sl g_outc, Sl pre, Sl pre_c,
+template <class P>
+__global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl<typename P::T> g_out, Sl<typename P::T> g_outc,
+                                                             Sl<typename P::T> pre, Sl<typename P::T> pre_c,
                                                              const float* __restrict__ ch,
                                                              const float* __restrict__ sp,
                                                              const float* __restrict__ pools,  // (B,2,128)
@@ -71,20 +61,21 @@ __global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl g_out, Sl g_outc
                                                              float* __restrict__ part_gch,     // (B,nt,64)
                                                              int* __restrict__ part_arg,       // (B,nt,128)
                                                              long HW, int ntiles) {
-  constexpr int NJ = 8 / VEC;
   __shared__ float red_s[64][4];
   __shared__ int red_a[128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, b = blockIdx.y;
-  long pix[NJ];
-  bool ok[NJ];
+  const long tile0 = (long)tile * BWD_TILE;
+  bool ok[8];
+  int pidx[8];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    pix[j] = (long)tile * BWD_TILE + (long)j * (256 * VEC) + tid * VEC;
-    ok[j] = pix[j] < HW;
+  for (int i = 0; i < 8; ++i) {
+    const long q = P::pix(tile0, tid, i);
+    ok[i] = q < HW;
+    pidx[i] = (int)q;
   }
   float spv[8], gsp[8];
-  load8<VEC>(sp + (long)b * HW, pix, ok, spv);
+  P::loadf(sp + (long)b * HW, tile0, tid, HW, spv);
 #pragma unroll
   for (int i = 0; i < 8; ++i) gsp[i] = 0.f;
   const float* mx = pools + ((long)b * 2 + 1) * 128;
@@ -92,23 +83,21 @@ __global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl g_out, Sl g_outc
 #pragma unroll 1
   for (int c = 0; c < 64; ++c) {
     float go[8], gc[8], p[8], pc[8];
-    load8<VEC>(g_out.p + b * g_out.img + c * HW, pix, ok, go);
-    load8<VEC>(g_outc.p + b * g_outc.img + c * HW, pix, ok, gc);
-    load8<VEC>(pre.p + b * pre.img + c * HW, pix, ok, p);
-    load8<VEC>(pre_c.p + b * pre_c.img + c * HW, pix, ok, pc);
+    P::load(g_out.p + b * g_out.img + c * HW, tile0, tid, HW, go);
+    P::load(g_outc.p + b * g_outc.img + c * HW, tile0, tid, HW, gc);
+    P::load(pre.p + b * pre.img + c * HW, tile0, tid, HW, p);
+    P::load(pre_c.p + b * pre_c.img + c * HW, tile0, tid, HW, pc);
     const float chc = ch[b * 64 + c];
     const float mxc = mx[c], mxd = mx[64 + c];  // Fcat order: colour c, depth 64+c
     float s = 0.f;
     int ad = INT_MAX, ac = INT_MAX;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bool k = ok[i / VEC];
       const float gg = go[i] * p[i] + gc[i] * pc[i];
       s = fmaf(gg, spv[i], s);
       gsp[i] = fmaf(gg, chc, gsp[i]);
-      const int pi = (int)(pix[i / VEC] + (VEC == 4 ? (i & 3) : 0));
-      if (k && p[i] == mxd) ad = min(ad, pi);
-      if (k && pc[i] == mxc) ac = min(ac, pi);
+      if (ok[i] && p[i] == mxd) ad = min(ad, pidx[i]);
+      if (ok[i] && pc[i] == mxc) ac = min(ac, pidx[i]);
     }
     s = wsum(s);
     ad = wmin(ad);
@@ -116,21 +105,9 @@ __global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl g_out, Sl g_outc
     if (lane == 0) { red_s[c][wave] = s; red_a[c][wave] = ac; red_a[64 + c][wave] = ad; }
   }
   // dL/dz = dL/dsp * sp * (1 - sp)
-  float* gz = g_z + (long)b * HW;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    if (!ok[j]) continue;
-    if constexpr (VEC == 4) {
-      float4 o;
-      o.x = gsp[4 * j] * spv[4 * j] * (1.f - spv[4 * j]);
-      o.y = gsp[4 * j + 1] * spv[4 * j + 1] * (1.f - spv[4 * j + 1]);
-      o.z = gsp[4 * j + 2] * spv[4 * j + 2] * (1.f - spv[4 * j + 2]);
-      o.w = gsp[4 * j + 3] * spv[4 * j + 3] * (1.f - spv[4 * j + 3]);
-      *reinterpret_cast<float4*>(gz + pix[j]) = o;
-    } else {
-      gz[pix[j]] = gsp[j] * spv[j] * (1.f - spv[j]);
-    }
-  }
+  for (int i = 0; i < 8; ++i) gsp[i] = gsp[i] * spv[i] * (1.f - spv[i]);
+  P::storef(g_z + (long)b * HW, tile0, tid, HW, gsp);
   __syncthreads();
   if (tid < 64)
     part_gch[((long)b * ntiles + tile) * 64 + tid] =
@@ -267,31 +244,29 @@ __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __res
 }
 
 // ---- D -------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void cac_bwd_apply_kernel(Sl g_out, Sl g_outc, Sl pre, Sl pre_c,
+template <class P>
+__global__ __launch_bounds__(256) void cac_bwd_apply_kernel(Sl<typename P::T> g_out, Sl<typename P::T> g_outc,
+                                                            Sl<typename P::T> pre, Sl<typename P::T> pre_c,
                                                             const float* __restrict__ ch,
                                                             const float* __restrict__ sp,
                                                             const float* __restrict__ pooled,    // (B,2,H,W): max, mean
                                                             const float* __restrict__ g_pooled,  // (B,2,H,W)
                                                             const float* __restrict__ g_pools,   // (B,2,128): avg, max
                                                             const int* __restrict__ argpix,      // (B,128)
-                                                            SlW g_pre, SlW g_pre_c, SlW g_in, SlW g_in_c,
+                                                            SlW<typename P::T> g_pre, SlW<typename P::T> g_pre_c,
+                                                            SlW<typename P::T> g_in, SlW<typename P::T> g_in_c,
                                                             int accumulate_in, long HW, float inv_hw) {
-  constexpr int NJ = 8 / VEC;
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, b = blockIdx.y;
-  long pix[NJ];
-  bool ok[NJ];
+  const long tile0 = (long)tile * BWD_TILE;
+  int pidx[8];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    pix[j] = (long)tile * BWD_TILE + (long)j * (256 * VEC) + tid * VEC;
-    ok[j] = pix[j] < HW;
-  }
+  for (int i = 0; i < 8; ++i) pidx[i] = (int)P::pix(tile0, tid, i);
   float spv[8], pmax[8], gpmax[8], gpmean[8];
-  load8<VEC>(sp + (long)b * HW, pix, ok, spv);
-  load8<VEC>(pooled + (long)b * 2 * HW, pix, ok, pmax);
-  load8<VEC>(g_pooled + (long)b * 2 * HW, pix, ok, gpmax);
-  load8<VEC>(g_pooled + (long)b * 2 * HW + HW, pix, ok, gpmean);
+  P::loadf(sp + (long)b * HW, tile0, tid, HW, spv);
+  P::loadf(pooled + (long)b * 2 * HW, tile0, tid, HW, pmax);
+  P::loadf(g_pooled + (long)b * 2 * HW, tile0, tid, HW, gpmax);
+  P::loadf(g_pooled + (long)b * 2 * HW + HW, tile0, tid, HW, gpmean);
   bool done[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { done[i] = false; gpmean[i] *= (1.f / 128.f); }
@@ -303,74 +278,61 @@ __global__ __launch_bounds__(256) void cac_bwd_apply_kernel(Sl g_out, Sl g_outc,
   for (int fc = 0; fc < 128; ++fc) {  // Fcat order: colour first, so ties route like torch.max(dim=1)
     const bool colour = fc < 64;
     const int c = fc & 63;
-    const Sl& go_s = colour ? g_outc : g_out;
-    const Sl& pr_s = colour ? pre_c : pre;
-    const SlW& gp_s = colour ? g_pre_c : g_pre;
-    const SlW& gi_s = colour ? g_in_c : g_in;
+    const Sl<typename P::T>& go_s = colour ? g_outc : g_out;
+    const Sl<typename P::T>& pr_s = colour ? pre_c : pre;
+    const SlW<typename P::T>& gp_s = colour ? g_pre_c : g_pre;
+    const SlW<typename P::T>& gi_s = colour ? g_in_c : g_in;
     float go[8], p[8], gi[8];
-    load8<VEC>(go_s.p + b * go_s.img + c * HW, pix, ok, go);
-    load8<VEC>(pr_s.p + b * pr_s.img + c * HW, pix, ok, p);
-    if (accumulate_in) load8<VEC>(gi_s.p + b * gi_s.img + c * HW, pix, ok, gi);
+    P::load(go_s.p + b * go_s.img + c * HW, tile0, tid, HW, go);
+    P::load(pr_s.p + b * pr_s.img + c * HW, tile0, tid, HW, p);
+    if (accumulate_in) P::load(gi_s.p + b * gi_s.img + c * HW, tile0, tid, HW, gi);
     const float chc = ch[b * 64 + c];
     const float ga = gavg[fc] * inv_hw, gm = gmax[fc];
     const int apx = ap[fc];
     float o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int pi = (int)(pix[i / VEC] + (VEC == 4 ? (i & 3) : 0));
       float v = go[i] * (chc * spv[i]) + ga + gpmean[i];
-      if (pi == apx) v += gm;
+      if (pidx[i] == apx) v += gm;
       const bool hit = !done[i] && p[i] == pmax[i];
       if (hit) v += gpmax[i];
       done[i] = done[i] || hit;
       o[i] = v;
       gi[i] = accumulate_in ? gi[i] + go[i] : go[i];
     }
-    float* gpo = gp_s.p + b * gp_s.img + c * HW;
-    float* gio = gi_s.p + b * gi_s.img + c * HW;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (!ok[j]) continue;
-      if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(gpo + pix[j]) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
-        *reinterpret_cast<float4*>(gio + pix[j]) = make_float4(gi[4 * j], gi[4 * j + 1], gi[4 * j + 2], gi[4 * j + 3]);
-      } else {
-        gpo[pix[j]] = o[j];
-        gio[pix[j]] = gi[j];
-      }
-    }
+    P::store(gp_s.p + b * gp_s.img + c * HW, tile0, tid, HW, o);
+    P::store(gi_s.p + b * gi_s.img + c * HW, tile0, tid, HW, gi);
   }
 }
 
 // ---- elementwise: dst = [dst +] src, then dst = mask > 0 ? dst : 0 ---------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void ew_add_mask_kernel(float* __restrict__ dst, long d_img,
-                                                          const float* __restrict__ src, long s_img,
-                                                          const float* __restrict__ mask, long m_img, int C,
+template <class P>
+__global__ __launch_bounds__(256) void ew_add_mask_kernel(typename P::T* __restrict__ dst, long d_img,
+                                                          const typename P::T* __restrict__ src, long s_img,
+                                                          const typename P::T* __restrict__ mask, long m_img, int C,
                                                           long HW, int accumulate) {
   const int bc = blockIdx.y;
   const int b = bc / C, c = bc % C;
-  const long pix = (blockIdx.x * 256L + threadIdx.x) * VEC;
-  if (pix >= HW) return;
-  float* d = dst + b * d_img + c * HW + pix;
-  if constexpr (VEC == 4) {
-    float4 v = accumulate || !src ? *reinterpret_cast<const float4*>(d) : make_float4(0, 0, 0, 0);
-    if (src) {
-      const float4 s = *reinterpret_cast<const float4*>(src + b * s_img + c * HW + pix);
-      v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-    }
-    if (mask) {
-      const float4 m = *reinterpret_cast<const float4*>(mask + b * m_img + c * HW + pix);
-      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-      v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(d) = v;
-  } else {
-    float v = accumulate || !src ? *d : 0.f;
-    if (src) v += src[b * s_img + c * HW + pix];
-    if (mask) v = mask[b * m_img + c * HW + pix] > 0.f ? v : 0.f;
-    *d = v;
+  const int tid = threadIdx.x;
+  const long tile0 = (long)blockIdx.x * PX_TILE;
+  float v[8], t[8];
+  typename P::T* d = dst + b * d_img + c * HW;
+  if (accumulate || !src) P::load(d, tile0, tid, HW, v);
+  else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
   }
+  if (src) {
+    P::load(src + b * s_img + c * HW, tile0, tid, HW, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += t[i];
+  }
+  if (mask) {
+    P::load(mask + b * m_img + c * HW, tile0, tid, HW, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
+  }
+  P::store(d, tile0, tid, HW, v);
 }
 
 // ---- host ------------------------------------------------------------------------------------------
@@ -378,24 +340,31 @@ static bool al16(const void* a, const void* b = nullptr, const void* c = nullptr
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d)) % 16) == 0;
 }
-static Sl mk(const codon_tensor* t, long HW) { return Sl{(const float*)t->data + t->coff * HW, t->ctotal * HW}; }
-static SlW mkw(const codon_tensor* t, long HW) { return SlW{(float*)t->data + t->coff * HW, t->ctotal * HW}; }
+template <class T>
+static Sl<T> mk(const codon_tensor* t, long HW) { return Sl<T>{(const T*)t->data + t->coff * HW, t->ctotal * HW}; }
+template <class T>
+static SlW<T> mkw(const codon_tensor* t, long HW) { return SlW<T>{(T*)t->data + t->coff * HW, t->ctotal * HW}; }
+static const char* basep(const codon_tensor* t, long HW, int dtype) {
+  return (const char*)t->data + t->coff * HW * (dtype == CODON_BF16 ? 2 : 4);
+}
 
 int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }
 int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W + 255) / 256); }
 
 int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
                    const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
-                   const float* pools, float* g_z, float* part_gch, int* part_arg, hipStream_t stream) {
+                   const float* pools, float* g_z, float* part_gch, int* part_arg, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
   const int nt = cac_bwd_tiles(H, W);
-  const Sl a = mk(g_out, HW), b = mk(g_outc, HW), c = mk(pre, HW), d = mk(pre_c, HW);
-  if (HW % 4 == 0 && al16(a.p, b.p, c.p, d.p) && al16(sp, g_z))
-    hipLaunchKernelGGL(cac_bwd_reduce_kernel<4>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pools, g_z,
-                       part_gch, part_arg, HW, nt);
-  else
-    hipLaunchKernelGGL(cac_bwd_reduce_kernel<1>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pools, g_z,
-                       part_gch, part_arg, HW, nt);
+  const bool al = al16(basep(g_out, HW, dtype), basep(g_outc, HW, dtype), basep(pre, HW, dtype),
+                       basep(pre_c, HW, dtype)) && al16(sp, g_z);
+  px_dispatch(dtype, HW, al, [&](auto pol) {
+    using P = decltype(pol);
+    using T = typename P::T;
+    hipLaunchKernelGGL(cac_bwd_reduce_kernel<P>, dim3(nt, B), dim3(256), 0, stream, mk<T>(g_out, HW),
+                       mk<T>(g_outc, HW), mk<T>(pre, HW), mk<T>(pre_c, HW), ch, sp, pools, g_z, part_gch, part_arg, HW,
+                       nt);
+  });
   return check_launch("cac_bwd_reduce_kernel");
 }
 
@@ -434,38 +403,40 @@ int cac_bwd_apply(int B, int H, int W, const codon_tensor* g_out, const codon_te
                   const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
                   const float* pooled, const float* g_pooled, const float* g_pools, const int* argpix,
                   const codon_tensor* g_pre, const codon_tensor* g_pre_c, const codon_tensor* g_in,
-                  const codon_tensor* g_in_c, int accumulate_in, hipStream_t stream) {
+                  const codon_tensor* g_in_c, int accumulate_in, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
   const int nt = cac_bwd_tiles(H, W);
-  const Sl a = mk(g_out, HW), b = mk(g_outc, HW), c = mk(pre, HW), d = mk(pre_c, HW);
-  const SlW e = mkw(g_pre, HW), f = mkw(g_pre_c, HW), g = mkw(g_in, HW), h = mkw(g_in_c, HW);
   const float inv = (float)(1.0 / (double)HW);
-  if (HW % 4 == 0 && al16(a.p, b.p, c.p, d.p) && al16(e.p, f.p, g.p, h.p) && al16(sp, pooled, g_pooled))
-    hipLaunchKernelGGL(cac_bwd_apply_kernel<4>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pooled,
-                       g_pooled, g_pools, argpix, e, f, g, h, accumulate_in, HW, inv);
-  else
-    hipLaunchKernelGGL(cac_bwd_apply_kernel<1>, dim3(nt, B), dim3(256), 0, stream, a, b, c, d, ch, sp, pooled,
-                       g_pooled, g_pools, argpix, e, f, g, h, accumulate_in, HW, inv);
+  const bool al = al16(basep(g_out, HW, dtype), basep(g_outc, HW, dtype), basep(pre, HW, dtype),
+                       basep(pre_c, HW, dtype)) &&
+                  al16(basep(g_pre, HW, dtype), basep(g_pre_c, HW, dtype), basep(g_in, HW, dtype),
+                       basep(g_in_c, HW, dtype)) && al16(sp, pooled, g_pooled);
+  px_dispatch(dtype, HW, al, [&](auto pol) {
+    using P = decltype(pol);
+    using T = typename P::T;
+    hipLaunchKernelGGL(cac_bwd_apply_kernel<P>, dim3(nt, B), dim3(256), 0, stream, mk<T>(g_out, HW),
+                       mk<T>(g_outc, HW), mk<T>(pre, HW), mk<T>(pre_c, HW), ch, sp, pooled, g_pooled, g_pools, argpix,
+                       mkw<T>(g_pre, HW), mkw<T>(g_pre_c, HW), mkw<T>(g_in, HW), mkw<T>(g_in_c, HW), accumulate_in,
+                       HW, inv);
+  });
   return check_launch("cac_bwd_apply_kernel");
 }
 
 int ew_add_mask(int B, int H, int W, int C, const codon_tensor* dst, const codon_tensor* src,
-                const codon_tensor* mask, int accumulate, hipStream_t stream) {
+                const codon_tensor* mask, int accumulate, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
-  float* d = (float*)dst->data + dst->coff * HW;
-  const float* s = src ? (const float*)src->data + src->coff * HW : nullptr;
-  const float* m = mask ? (const float*)mask->data + mask->coff * HW : nullptr;
-  const long s_img = src ? src->ctotal * HW : 0, m_img = mask ? mask->ctotal * HW : 0;
   CODON_REQUIRE((long)B * C <= 65535, CODON_ERR_UNSUPPORTED, "ew_add_mask: batch*channels too large");
-  if (HW % 4 == 0 && al16(d, s, m)) {
-    const unsigned gx = (unsigned)((HW / 4 + 255) / 256);
-    hipLaunchKernelGGL(ew_add_mask_kernel<4>, dim3(gx, B * C), dim3(256), 0, stream, d, dst->ctotal * HW, s, s_img, m,
-                       m_img, C, HW, accumulate);
-  } else {
-    const unsigned gx = (unsigned)((HW + 255) / 256);
-    hipLaunchKernelGGL(ew_add_mask_kernel<1>, dim3(gx, B * C), dim3(256), 0, stream, d, dst->ctotal * HW, s, s_img, m,
-                       m_img, C, HW, accumulate);
-  }
+  const char* d = basep(dst, HW, dtype);
+  const char* s = src ? basep(src, HW, dtype) : nullptr;
+  const char* m = mask ? basep(mask, HW, dtype) : nullptr;
+  const long s_img = src ? src->ctotal * HW : 0, m_img = mask ? mask->ctotal * HW : 0;
+  const unsigned nt = (unsigned)((HW + PX_TILE - 1) / PX_TILE);
+  px_dispatch(dtype, HW, al16(d, s, m), [&](auto pol) {
+    using P = decltype(pol);
+    using T = typename P::T;
+    hipLaunchKernelGGL(ew_add_mask_kernel<P>, dim3(nt, B * C), dim3(256), 0, stream, (T*)d, dst->ctotal * HW,
+                       (const T*)s, s_img, (const T*)m, m_img, C, HW, accumulate);
+  });
   return check_launch("ew_add_mask_kernel");
 }
 

@@ -31,21 +31,25 @@ int conv_ck(int ks);
 int conv2d_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, hipStream_t);
 size_t conv_wgrad_workspace_bytes(const codon_conv_desc*);
 int conv2d_wgrad_f32(const codon_conv_desc*, const float*, const float*, float*, float*, size_t, int, hipStream_t);
+size_t conv_wgrad_bf16_workspace_bytes(const codon_conv_desc*);
+int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
 int stem_fwd(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
 size_t conv1ch_wgrad_workspace_bytes(int, int, int);
-int conv1ch_wgrad(int, int, int, const float*, int, int, const float*, float*, int, float*, size_t, hipStream_t);
+int conv1ch_wgrad(int, int, int, const void*, int, int, const float*, float*, int, float*, size_t, int, hipStream_t);
 int cac_bwd_tiles(int, int);
 int cac_bwd_spatial_blocks(int, int, int);
 int cac_bwd_reduce(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
-                   const float*, const float*, const float*, float*, float*, int*, hipStream_t);
+                   const float*, const float*, const float*, float*, float*, int*, int, hipStream_t);
 int cac_bwd_gate(int, int, int, const float*, const int*, const float*, const float*, const float*, const float*,
                  const float*, float*, int*, float*, float*, float*, float*, float*, hipStream_t);
 int cac_bwd_spatial(int, int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 int cac_bwd_apply(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
                   const float*, const float*, const float*, const float*, const float*, const int*,
-                  const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
-int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
+                  const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int,
+                  hipStream_t);
+int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int,
+                hipStream_t);
 int head_fwd(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
 int cac_stats_tiles(int, int);
 int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t);
@@ -119,6 +123,7 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
 
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {
   if (!d || !shape_ok(d->batch, d->height, d->width)) return 0;
+  if (d->dtype == CODON_BF16) return conv_wgrad_bf16_workspace_bytes(d);
   return conv_wgrad_workspace_bytes(d);
 }
 
@@ -129,6 +134,8 @@ int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, 
   CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
                     d->y_coff + d->cout <= d->y_ctotal,
                 CODON_ERR_BAD_ARG, "conv2d_wgrad: channel slice outside its buffer");
+  if (d->dtype == CODON_BF16)
+    return conv2d_wgrad_bf16(d, x, gy, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d", d->dtype);
   return conv2d_wgrad_f32(d, (const float*)x, (const float*)gy, dw, (float*)workspace, workspace_bytes, accumulate,
                           (hipStream_t)stream);
@@ -214,20 +221,24 @@ size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_
 }
 
 int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a, const float* s,
-                        float* dw, int32_t flip, void* workspace, size_t workspace_bytes, codon_stream_t stream) {
+                        float* dw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t dtype,
+                        codon_stream_t stream) {
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "conv1ch_wgrad: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(a) && s && dw && workspace, CODON_ERR_BAD_ARG, "conv1ch_wgrad: null pointer or bad slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "conv1ch_wgrad: bad shape");
-  return conv1ch_wgrad(batch, height, width, (const float*)a->data, a->ctotal, a->coff, s, dw, flip,
-                       (float*)workspace, workspace_bytes, (hipStream_t)stream);
+  return conv1ch_wgrad(batch, height, width, a->data, a->ctotal, a->coff, s, dw, flip, (float*)workspace,
+                       workspace_bytes, dtype, (hipStream_t)stream);
 }
 
 int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst,
-                      const codon_tensor* src, const codon_tensor* mask, int32_t accumulate, codon_stream_t stream) {
+                      const codon_tensor* src, const codon_tensor* mask, int32_t accumulate, int32_t dtype,
+                      codon_stream_t stream) {
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "ew_add_mask: dtype %d", dtype);
   auto ok = [&](const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + channels <= t->ctotal; };
   CODON_REQUIRE(channels > 0 && ok(dst) && (!src || ok(src)) && (!mask || ok(mask)), CODON_ERR_BAD_ARG,
                 "ew_add_mask: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ew_add_mask: bad shape");
-  return ew_add_mask(batch, height, width, channels, dst, src, mask, accumulate, (hipStream_t)stream);
+  return ew_add_mask(batch, height, width, channels, dst, src, mask, accumulate, dtype, (hipStream_t)stream);
 }
 
 int32_t codon_cac_bwd_tiles(int32_t height, int32_t width) {
@@ -240,13 +251,14 @@ int32_t codon_cac_bwd_spatial_blocks(int32_t batch, int32_t height, int32_t widt
 int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
                          const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
                          const float* ch, const float* sp, const float* pools, float* g_z, float* part_gch,
-                         int32_t* part_arg, codon_stream_t stream) {
+                         int32_t* part_arg, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_bwd_reduce: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pools &&
                     g_z && part_gch && part_arg,
                 CODON_ERR_BAD_ARG, "cac_bwd_reduce: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_reduce: bad shape");
   return cac_bwd_reduce(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg,
-                        (hipStream_t)stream);
+                        dtype, (hipStream_t)stream);
 }
 
 int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch, const int32_t* part_arg,
@@ -276,14 +288,15 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
                         const float* ch, const float* sp, const float* pooled, const float* g_pooled,
                         const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
                         const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
-                        int32_t accumulate_in, codon_stream_t stream) {
+                        int32_t accumulate_in, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_bwd_apply: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pooled &&
                     g_pooled && g_pools && argpix && slice_ok(g_pre) && slice_ok(g_pre_c) && slice_ok(g_in) &&
                     slice_ok(g_in_c),
                 CODON_ERR_BAD_ARG, "cac_bwd_apply: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_apply: bad shape");
   return cac_bwd_apply(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pooled, g_pooled, g_pools, argpix,
-                       g_pre, g_pre_c, g_in, g_in_c, accumulate_in, (hipStream_t)stream);
+                       g_pre, g_pre_c, g_in, g_in_c, accumulate_in, dtype, (hipStream_t)stream);
 }
 
 int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, int32_t scale, const float* lr,

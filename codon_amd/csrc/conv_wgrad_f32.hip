@@ -171,6 +171,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *o = accumulate ? *o + s : s;
 }
 
+int launch_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
+                        hipStream_t stream) {
+  const long n = (long)cout * cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, dw, cout, cin,
+                     taps, nsplit, accumulate);
+  return check_launch("wgrad_reduce_kernel");
+}
+
 struct WgradPlan {
   int co_t, ci_t, nbands, band_tiles_y, nsplit, nchan_blocks;
 };
@@ -227,10 +235,7 @@ int conv2d_wgrad_f32(const codon_conv_desc* d, const float* x, const float* gy, 
   else launch_wgrad<1, 2, 2>(p, pl.nchan_blocks, stream);
   int st = check_launch("conv_wgrad_f32_kernel");
   if (st != CODON_OK) return st;
-  const long n = (long)d->cout * d->cin * d->ksize * d->ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, dw,
-                     d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate);
-  return check_launch("wgrad_reduce_kernel");
+  return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
 }
 
 }  // namespace codon

@@ -234,14 +234,15 @@ int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const
 // 16 k-steps out of L1).  0.01 % of the FLOPs: simplicity over speed.  Per-wave partials -> fixed-order sum.
 constexpr int W1_ROWS = 8;  // image rows per workgroup (2 per wave)
 
-__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restrict__ a, long a_img, long a_base,
+template <typename T>
+__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const T* __restrict__ a, long a_img, long a_base,
                                                             const float* __restrict__ s, float* __restrict__ part,
                                                             int H, int W, int nrowblk) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, k = lane >> 5;
   const int b = blockIdx.x / nrowblk, rb = blockIdx.x % nrowblk;
   const long HW = (long)H * W;
-  const float* ab = a + b * a_img + a_base;
+  const T* ab = a + b * a_img + a_base;
   const float* sb = s + (long)b * HW;
   const int dy = l31 / 3 - 1, dx = l31 % 3 - 1;
   f32x16 acc0, acc1;
@@ -252,14 +253,14 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float* __restr
     if (y >= H) break;
     const int yy = y + dy;
     const bool yok = l31 < 9 && yy >= 0 && yy < H;
-    const float* a0 = ab + (long)l31 * HW + (long)y * W;
-    const float* a1 = a0 + 32 * HW;
+    const T* a0 = ab + (long)l31 * HW + (long)y * W;
+    const T* a1 = a0 + 32 * HW;
     const float* srow = sb + (long)yy * W;
     for (int x0 = 0; x0 < W; x0 += 2) {
       const int x = x0 + k;
       const bool xin = x < W;
-      const float va0 = xin ? a0[x] : 0.f;
-      const float va1 = xin ? a1[x] : 0.f;
+      const float va0 = xin ? ldx(a0 + x) : 0.f;
+      const float va1 = xin ? ldx(a1 + x) : 0.f;
       const int xx = x + dx;
       const float vb = (yok && xin && xx >= 0 && xx < W) ? srow[xx] : 0.f;
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc0, 0, 0, 0);
@@ -293,14 +294,18 @@ size_t conv1ch_wgrad_workspace_bytes(int B, int H, int W) {
   return (size_t)B * nrowblk * 4 * 576 * sizeof(float);
 }
 
-int conv1ch_wgrad(int B, int H, int W, const float* a, int a_ctotal, int a_coff, const float* s, float* dw, int flip,
-                  float* ws, size_t ws_bytes, hipStream_t stream) {
+int conv1ch_wgrad(int B, int H, int W, const void* a, int a_ctotal, int a_coff, const float* s, float* dw, int flip,
+                  float* ws, size_t ws_bytes, int dtype, hipStream_t stream) {
   CODON_REQUIRE(ws_bytes >= conv1ch_wgrad_workspace_bytes(B, H, W), CODON_ERR_BAD_ARG,
                 "conv1ch_wgrad: workspace too small");
   const long HW = (long)H * W;
   const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
-  hipLaunchKernelGGL(conv1ch_wgrad_kernel, dim3(B * nrowblk), dim3(256), 0, stream, a, a_ctotal * HW, a_coff * HW, s,
-                     ws, H, W, nrowblk);
+  if (dtype == CODON_BF16)
+    hipLaunchKernelGGL(conv1ch_wgrad_kernel<u16_t>, dim3(B * nrowblk), dim3(256), 0, stream, (const u16_t*)a,
+                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
+  else
+    hipLaunchKernelGGL(conv1ch_wgrad_kernel<float>, dim3(B * nrowblk), dim3(256), 0, stream, (const float*)a,
+                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
   int st = check_launch("conv1ch_wgrad_kernel");
   if (st != CODON_OK) return st;
   hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(3), dim3(256), 0, stream, ws, dw, B * nrowblk * 4, flip, 0);

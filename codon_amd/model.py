@@ -167,9 +167,6 @@ class _CODONBase(nn.Module):
             raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16)")
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
-            if adt != torch.float32:
-                raise NotImplementedError("codon_amd.CODONNet: the bf16 backward kernels are not built yet; "
-                                          "train in fp32 or run bf16 under torch.no_grad()")
             from .autograd import codon_apply  # training path (custom backward)
             return codon_apply(self, x, y)
         out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)

@@ -222,7 +222,7 @@ def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: torch.Tensor, flip: bool):
     at = a.ct()
     with torch.cuda.device(dev):
         L.check(lib.codon_conv1ch_wgrad(B, H, W, C.byref(at), _ptr(s), _ptr(dw), 1 if flip else 0, _ptr(ws), nbytes,
-                                        _stream(dev)), "conv1ch_wgrad")
+                                        _dt(a.buf), _stream(dev)), "conv1ch_wgrad")
 
 
 def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] = None, accumulate: bool = True):
@@ -233,7 +233,7 @@ def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] =
     with torch.cuda.device(dev):
         L.check(lib.codon_ew_add_mask(B, H, W, dst.c, C.byref(dt_), C.byref(st_) if st_ is not None else None,
                                       C.byref(mt_) if mt_ is not None else None, 1 if accumulate else 0,
-                                      _stream(dev)), "ew_add_mask")
+                                      _dt(dst.buf), _stream(dev)), "ew_add_mask")
 
 
 def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
@@ -262,7 +262,7 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
     with torch.cuda.device(dev):
         L.check(lib.codon_cac_bwd_reduce(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]),
                                          _ptr(ch), _ptr(sp), _ptr(pools), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
-                                         st), "cac_bwd_reduce")
+                                         _dt(pre.buf), st), "cac_bwd_reduce")
         L.check(lib.codon_cac_bwd_gate(B, H, W, _ptr(part_gch), _ptr(part_arg), _ptr(ch), _ptr(pools), _ptr(w1),
                                        _ptr(b1), _ptr(w2), _ptr(g_pools), _ptr(argpix), _ptr(part_param), _ptr(dw1),
                                        _ptr(db1), _ptr(dw2), _ptr(db2), st), "cac_bwd_gate")
@@ -271,5 +271,5 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
         L.check(lib.codon_cac_bwd_apply(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]),
                                         _ptr(ch), _ptr(sp), _ptr(pooled), _ptr(g_pooled), _ptr(g_pools),
                                         _ptr(argpix), C.byref(t[4]), C.byref(t[5]), C.byref(t[6]), C.byref(t[7]),
-                                        1 if accumulate_in else 0, st), "cac_bwd_apply")
+                                        1 if accumulate_in else 0, _dt(pre.buf), st), "cac_bwd_apply")
     return dw1, db1, dw2, db2, dws

@@ -136,6 +136,8 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
                         codon_stream_t stream);
 
 /* ---- backward (what torch.autograd computes for the reference) ------------
+ * dtype = codon_dtype of the 64/128-channel activation and gradient tensors (fp32 or bf16); 1-channel
+ * maps, gates, pooled maps and every parameter gradient are fp32.
  * The MFMA convs back-propagate through codon_conv2d_fwd (CODON_PACK_DGRAD weights, MASK_RELU /
  * ACCUM_OUT epilogues) and codon_conv2d_wgrad above; the entry points below cover the rest. */
 
@@ -153,12 +155,12 @@ int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const floa
 size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_t width);
 int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a,
                         const float* s, float* dw, int32_t flip, void* workspace,
-                        size_t workspace_bytes, codon_stream_t stream);
+                        size_t workspace_bytes, int32_t dtype, codon_stream_t stream);
 
 /* dst = [dst +] src (src may be NULL), then dst = mask > 0 ? dst : 0 (mask may be NULL); C channels. */
 int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels,
                       const codon_tensor* dst, const codon_tensor* src, const codon_tensor* mask,
-                      int32_t accumulate, codon_stream_t stream);
+                      int32_t accumulate, int32_t dtype, codon_stream_t stream);
 
 /* CAC gate backward, four launches (see codon_amd/csrc/cac_bwd.hip for the math):
  * reduce : g_z (B,1,H,W) = dL/d(spatial logits); part_gch (B,nt,64), part_arg (B,nt,128) int32,
@@ -174,7 +176,7 @@ int32_t codon_cac_bwd_spatial_blocks(int32_t batch, int32_t height, int32_t widt
 int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
                          const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
                          const float* ch, const float* sp, const float* pools, float* g_z,
-                         float* part_gch, int32_t* part_arg, codon_stream_t stream);
+                         float* part_gch, int32_t* part_arg, int32_t dtype, codon_stream_t stream);
 int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch,
                        const int32_t* part_arg, const float* ch, const float* pools, const float* w1,
                        const float* b1, const float* w2, float* g_pools, int32_t* argpix,
@@ -188,7 +190,7 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
                         const float* ch, const float* sp, const float* pooled, const float* g_pooled,
                         const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
                         const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
-                        int32_t accumulate_in, codon_stream_t stream);
+                        int32_t accumulate_in, int32_t dtype, codon_stream_t stream);
 
 /* ---- synthetic-input generator: x4 / x8 / x16 bicubic upsample ---------------------------------
  * No reference counterpart (the reference's depth inputs are upsampled offline,

@@ -219,3 +219,29 @@ def test_gradsync_flat_views_accumulate_in_place():
     with torch.no_grad():
         o2 = m2(x.cuda(), y.cuda())
     assert torch.equal(o1.detach(), o2)
+
+
+def test_bf16_training_gradients_vs_fp32_oracle():
+    """bf16 activations/gradients, fp32 accumulate, fp32 master weights and parameter gradients
+    (BASELINE configs[2]).  Tolerance: whole gradient vector rel-RMSE <= 5e-2 vs the fp32 oracle's autograd
+    (bf16 has 8 mantissa bits: ~4e-3 per rounding, ~40 layers deep); big tensors individually <= 8e-2."""
+    sd = orc.he_state("x4", seed=31)
+    g = np.random.default_rng(8)
+    B, H, W = 2, 40, 48
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    tgt = target_for(x)
+    _, gref, out_ref = orc.grads(sd, x, y, tgt)
+    m = _model("x4", sd).set_compute_dtype(torch.bfloat16)
+    out = m(x.cuda(), y.cuda())
+    assert out.dtype == torch.float32 and rel_rmse(out.detach().cpu(), out_ref) <= 3e-2
+    out.backward((torch.sign(out_ref - tgt) / out_ref.numel()).cuda())
+    num = den = 0.0
+    for k, p in m.named_parameters():
+        if k in gref:
+            assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+            if gref[k].numel() >= 36864:
+                assert rel_rmse(p.grad.cpu(), gref[k]) <= 8e-2, k
+            num += float((p.grad.cpu().double() - gref[k].double()).pow(2).sum())
+            den += float(gref[k].double().pow(2).sum())
+    assert (num / den) ** 0.5 <= 5e-2

@@ -287,3 +287,36 @@ def test_bf16_elementwise_kernels():
                       Slice(oc, 0, 64), Slice(oc, 64, 64))
         assert rel_rmse(oc[:, :64].float().cpu(), pre * g + in2[:, :64].float()) < 3e-3
         assert rel_rmse(oc[:, 64:].float().cpu(), pre_c * g + in2[:, 64:].float()) < 3e-3
+
+
+@pytest.mark.parametrize("k,cin,cout", WGRAD_CASES)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70), (1, 130, 40)])
+def test_conv2d_wgrad_bf16_vs_autograd(k, cin, cout, shape):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, cin, H, W), 1).bfloat16()
+    gy = _rand((B, cout, H, W), 3).bfloat16()
+    w = torch.zeros((cout, cin, k, k), requires_grad=True)
+    F.conv2d(x.float(), w, None, 1, k // 2).backward(gy.float())      # same bf16-rounded operands, fp32 math
+    dw = torch.full((cout, cin, k, k), float("nan"), device=dev)
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k)
+    assert dw.dtype == torch.float32
+    assert rel_rmse(dw.cpu(), w.grad) < 1e-5        # fp32 accumulate: only summation order differs
+    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k, accumulate=True)
+    assert rel_rmse(dw.cpu(), 2 * w.grad) < 1e-5
+
+
+def test_conv2d_wgrad_bf16_slices():
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 21, 37
+    xb = _rand((B, 128, H, W), 1).bfloat16()
+    gb = _rand((B, 128, H, W), 2).bfloat16()
+    w = torch.zeros((64, 64, 5, 5), requires_grad=True)
+    F.conv2d(xb[:, 64:].float(), w, None, 1, 2).backward(gb[:, :64].float())
+    dw = torch.empty((64, 64, 5, 5), device=dev)
+    ops.conv2d_wgrad(Slice(xb.to(dev), 64, 64), Slice(gb.to(dev), 0, 64), dw, 5)
+    assert rel_rmse(dw.cpu(), w.grad) < 1e-5
