@@ -186,6 +186,17 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// chunk c sums rows [c*per, min((c+1)*per, nrows)) of part (nrows, n) into row c*per (in place), fixed order
+__global__ __launch_bounds__(64) void partial_chunk_sum_kernel(float* __restrict__ part, int n, int nrows, int per) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const int r0 = blockIdx.x * per, r1 = min(r0 + per, nrows);
+  if (r0 >= nrows) { return; }
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += part[(long)r * n + i];
+  part[(long)r0 * n + i] = s;
+}
+
 // ---- C -------------------------------------------------------------------------------------------
 // g_pooled[c][q] = sum_{dy,dx} w[c][dy][dx] * g_z[q - (dy-2, dx-2)]
 // dW[c][dy][dx]  = sum_q g_z[q] * pooled[c][q + (dy-2, dx-2)]      (per-block partials)
@@ -395,7 +406,17 @@ int cac_bwd_spatial(int B, int H, int W, const float* g_z, const float* pooled, 
                      total);
   int st = check_launch("cac_bwd_spatial_kernel");
   if (st != CODON_OK) return st;
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nblk, 50L, 0);
+  // two-level fixed-order sum of the (nblk, 50) partials: 64 chunks in place, then the 64 chunk sums
+  const int nchunk = nblk < 64 ? 1 : 64;
+  const int per = (nblk + nchunk - 1) / nchunk;
+  if (nchunk > 1) {
+    hipLaunchKernelGGL(partial_chunk_sum_kernel, dim3(nchunk), dim3(64), 0, stream, part_w, 50, nblk, per);
+    st = check_launch("partial_chunk_sum_kernel");
+    if (st != CODON_OK) return st;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nchunk, 50L * per, 0);
+  } else {
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nblk, 50L, 0);
+  }
   return check_launch("partial_sum_kernel");
 }
 

@@ -218,6 +218,171 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   }
 }
 
+// ---- 1x1 convolution (confuse / confuse_c / confuse_fuse and their dgrad): HBM-bound -----------------
+// Y[co][pix] = sum_ci W[co][ci] X[ci][pix] is a plain GEMM over the flattened pixels of one image: no halo,
+// so no LDS at all.  A wave owns 64 consecutive pixels (two 32-pixel MFMA column tiles) and all COUT rows.
+// B fragment of lane (pixel l&31, half h) for k-step ks = channels 16ks+8h .. +7 of that pixel: eight 2-byte
+// loads straight from the NCHW planes (each plane contributes a 64-byte run per half-wave; the two column
+// tiles of the wave use the two halves of every 128-byte line).  A fragment = 16 bytes of the packed weight
+// image (<= 16 KB, L1/L2 resident), loaded straight from global.  Epilogue identical to the k x k kernel.
+// PAIRED = true (HW even): the wave's two 32-column MFMA tiles are the EVEN and the ODD pixels of its 64-pixel
+// run, so one 4-byte load per lane (pixel pair 2j, 2j+1 of one channel plane) feeds both tiles and a half-wave
+// touches one full 128-byte line per instruction; outputs / residual / mask are 4-byte accesses likewise.
+// PAIRED = false: tiles are pixels [0,32) and [32,64), 2-byte accesses (any HW).
+constexpr int C1_ITER = 1;  // >1 measured slower (4: 5.4 vs 3.2 ms): the wave is latency-bound, more workgroups hide it better
+template <int CIN, int COUT, bool PAIRED>
+__global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p) {
+  constexpr int NKS = CIN / 16, CT = COUT / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const long HW = (long)p.H * p.W;
+  const int b = blockIdx.y;
+  const u16* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
+  const uint4* __restrict__ wg = p.w;                      // [chunk=ks][dy=0][dx=0][cb (2)][cout] x 16 B
+  u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
+  const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+  const bool relu = p.flags & CODON_CONV_RELU;
+  const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+
+  // a workgroup owns C1_ITER * 256 consecutive pixels: each plane sees a 2 KB contiguous run per workgroup
+  // (DRAM-page friendly for the 64..256 channel planes touched); waves interleave 64-pixel groups
+#pragma unroll 1
+  for (int it = 0; it < C1_ITER; ++it) {
+  const long pix0 = (((long)blockIdx.x * C1_ITER + it) * 4 + wave) * 64;   // first pixel of this wave's group
+  if (pix0 >= HW) break;                                   // wave-uniform
+
+  f32x16 acc[2][CT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  // PAIRED: this lane's pixel pair starts at pp (tile 0 = pp, tile 1 = pp + 1); else tile i pixel = px[i]
+  const long pp = pix0 + 2 * l31;
+  const bool pok = pp < HW;                                // HW even: both pixels in or out together
+  long px[2];
+  bool ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    px[i] = PAIRED ? pp + i : pix0 + i * 32 + l31;
+    ok[i] = px[i] < HW;
+  }
+
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    bf16x8 a[CT], bv[2];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const uint4 v = wg[(ks * 2 + half) * COUT + t * 32 + l31];
+      a[t] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    if constexpr (PAIRED) {
+      const u16* src = xg + (long)(ks * 16 + half * 8) * HW + pp;
+      unsigned d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = pok ? *reinterpret_cast<const unsigned*>(src + j * HW) : 0u;
+      unsigned e[4], o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        e[j] = (d[2 * j] & 0xffffu) | (d[2 * j + 1] << 16);          // even pixel: channels 2j, 2j+1
+        o[j] = (d[2 * j] >> 16) | (d[2 * j + 1] & 0xffff0000u);      // odd pixel
+      }
+      const uint4 ve = make_uint4(e[0], e[1], e[2], e[3]), vo = make_uint4(o[0], o[1], o[2], o[3]);
+      bv[0] = *reinterpret_cast<const bf16x8*>(&ve);
+      bv[1] = *reinterpret_cast<const bf16x8*>(&vo);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u16* src = xg + (long)(ks * 16 + half * 8) * HW + px[i];
+        unsigned w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned lo = ok[i] ? src[(2 * j) * HW] : 0u;
+          const unsigned hi = ok[i] ? src[(2 * j + 1) * HW] : 0u;
+          w4[j] = lo | (hi << 16);
+        }
+        const uint4 v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        bv[i] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], bv[i], acc[i][t], 0, 0, 0);
+  }
+
+  if constexpr (PAIRED) {
+    if (pok) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v0 = acc[0][t][r], v1 = acc[1][t][r];
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (rg) {
+          const unsigned m = *reinterpret_cast<const unsigned*>(rg + co * HW + pp);
+          const float m0 = __uint_as_float(m << 16), m1 = __uint_as_float(m & 0xffff0000u);
+          if (addr) { v0 += m0; v1 += m1; }
+          if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
+        }
+        if (accum) {
+          const unsigned m = *reinterpret_cast<const unsigned*>(yg + co * HW + pp);
+          v0 += __uint_as_float(m << 16); v1 += __uint_as_float(m & 0xffff0000u);
+        }
+        *reinterpret_cast<unsigned*>(yg + co * HW + pp) = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+      }
+    }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!ok[i]) continue;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][t][r];
+          if (relu) v = fmaxf(v, 0.f);
+          if (addr) v += bf16_to_f32(rg[co * HW + px[i]]);
+          if (mask) v = bf16_to_f32(rg[co * HW + px[i]]) > 0.f ? v : 0.f;
+          if (accum) v += bf16_to_f32(yg[co * HW + px[i]]);
+          yg[co * HW + px[i]] = f32_to_bf16(v);
+        }
+      }
+    }
+  }
+  }  // it
+}
+
+template <int CIN, int COUT>
+static int launch_conv1x1_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                             hipStream_t stream) {
+  Conv16Params p;
+  p.x = (const u16*)x; p.w = (const uint4*)w; p.y = (u16*)y; p.res = (const u16*)res;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = d->r_ctotal * HW;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
+  p.tiles_x = p.tiles_y = p.nblk = 0;
+  p.flags = d->flags;
+  CODON_REQUIRE(d->batch <= 65535, CODON_ERR_UNSUPPORTED, "conv2d_fwd: batch %d > 65535", d->batch);
+  const unsigned gx = (unsigned)((HW + 256 * C1_ITER - 1) / (256 * C1_ITER));
+  const bool al4 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                     reinterpret_cast<uintptr_t>(res)) % 4) == 0;
+  if (HW % 2 == 0 && al4)
+    hipLaunchKernelGGL((conv1x1_bf16_kernel<CIN, COUT, true>), dim3(gx, d->batch), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv1x1_bf16_kernel<CIN, COUT, false>), dim3(gx, d->batch), dim3(256), 0, stream, p);
+  return check_launch("conv1x1_bf16_kernel");
+}
+
 // OIHW fp32 -> bf16 packed [chunk][dy][dx][cb (2)][cout][8 ch]; DGRAD: flipped taps, in/out swapped.
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks,
                                         int dgrad) {
@@ -267,8 +432,8 @@ int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void
     case 3064064: return launch_conv16<3, 64, 64>(d, x, w, y, res, stream);
     case 3128064: return launch_conv16<3, 128, 64>(d, x, w, y, res, stream);
     case 3064128: return launch_conv16<3, 64, 128>(d, x, w, y, res, stream);
-    case 1128064: return launch_conv16<1, 128, 64>(d, x, w, y, res, stream);
-    case 1064128: return launch_conv16<1, 64, 128>(d, x, w, y, res, stream);
+    case 1128064: return launch_conv1x1_16<128, 64>(d, x, w, y, res, stream);
+    case 1064128: return launch_conv1x1_16<64, 128>(d, x, w, y, res, stream);
     default:
       set_error("conv2d_fwd: no bf16 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
       return CODON_ERR_UNSUPPORTED;
