@@ -17,7 +17,7 @@ ABI_VERSION = 1
 LIB_NAME = "libcodon_hip.so"
 
 OK = 0
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU = 1, 2, 4, 8
 PACK_FWD, PACK_DGRAD = 0, 1
 

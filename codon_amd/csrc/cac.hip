@@ -188,7 +188,7 @@ int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tenso
   const long HW = (long)H * W;
   const int nt = cac_stats_tiles(H, W);
   CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
-  const size_t es = dtype == CODON_BF16 ? 2 : 4;
+  const size_t es = dtype == CODON_F32 ? 4 : 2;
   const char* pre_c = (const char*)pc->data + pc->coff * HW * es;
   const char* pre = (const char*)pd->data + pd->coff * HW * es;
   px_dispatch(dtype, HW, aligned16(pre_c, pre, pooled), [&](auto pol) {
@@ -220,7 +220,7 @@ int cac_apply_fwd(int B, int H, int W, const codon_tensor* pre, const codon_tens
                   const codon_tensor* out_c, int dtype, hipStream_t stream) {
   const long HW = (long)H * W;
   CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: batch %d too large", B);
-  const size_t es = dtype == CODON_BF16 ? 2 : 4;
+  const size_t es = dtype == CODON_F32 ? 4 : 2;
   auto base = [&](const codon_tensor* t) { return (char*)t->data + t->coff * HW * es; };
   const bool al = aligned16(base(pre), base(in), base(out), sp) && aligned16(base(pre_c), base(in_c), base(out_c));
   const unsigned nt = (unsigned)((HW + PX_TILE - 1) / PX_TILE);

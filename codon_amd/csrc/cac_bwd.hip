@@ -356,7 +356,7 @@ static Sl<T> mk(const codon_tensor* t, long HW) { return Sl<T>{(const T*)t->data
 template <class T>
 static SlW<T> mkw(const codon_tensor* t, long HW) { return SlW<T>{(T*)t->data + t->coff * HW, t->ctotal * HW}; }
 static const char* basep(const codon_tensor* t, long HW, int dtype) {
-  return (const char*)t->data + t->coff * HW * (dtype == CODON_BF16 ? 2 : 4);
+  return (const char*)t->data + t->coff * HW * (dtype == CODON_F32 ? 4 : 2);
 }
 
 int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }

@@ -54,7 +54,7 @@ int head_fwd(int, int, int, const void*, int, int, const float*, const float*, f
 int cac_stats_tiles(int, int);
 int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t);
 int conv2d_fwd_bf16(const codon_conv_desc*, const void*, const void*, void*, const void*, hipStream_t);
-int pack_weight_bf16(const float*, void*, int, int, int, int, hipStream_t);
+int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int cac_gate_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
                  hipStream_t);
 int cac_spatial_fwd(int, int, int, const float*, const float*, float*, hipStream_t);
@@ -79,7 +79,7 @@ const char* codon_last_error_string(void) { return g_err; }
 
 size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t dtype) {
   if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 5)) return 0;
-  return (size_t)cout * cin * ksize * ksize * (dtype == CODON_BF16 ? 2 : 4);
+  return (size_t)cout * cin * ksize * ksize * (dtype == CODON_F32 ? 4 : 2);
 }
 
 int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, int32_t cin, int32_t ksize,
@@ -90,9 +90,9 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
   const int kin = mode == CODON_PACK_DGRAD ? cout : cin;
   CODON_REQUIRE(cout > 0 && cin > 0 && kin % conv_ck(ksize) == 0, CODON_ERR_UNSUPPORTED,
                 "conv_pack_weight: cin=%d cout=%d not a multiple of the channel chunk", cin, cout);
-  if (dtype == CODON_BF16) {
-    CODON_REQUIRE(kin % 16 == 0, CODON_ERR_UNSUPPORTED, "conv_pack_weight: bf16 needs cin %% 16 == 0");
-    return pack_weight_bf16(w_oihw, w_packed, cout, cin, ksize, mode, (hipStream_t)stream);
+  if (dtype == CODON_BF16 || dtype == CODON_F16) {
+    CODON_REQUIRE(kin % 16 == 0, CODON_ERR_UNSUPPORTED, "conv_pack_weight: 16-bit packing needs cin %% 16 == 0");
+    return pack_weight_bf16(w_oihw, w_packed, cout, cin, ksize, mode, dtype, (hipStream_t)stream);
   }
   CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: dtype %d", dtype);
   return pack_weight_f32(w_oihw, (float*)w_packed, cout, cin, ksize, mode, (hipStream_t)stream);
@@ -115,7 +115,8 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
                   "conv2d_fwd: residual slice outside its buffer");
   }
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_fwd: packed weights not 16-byte aligned");
-  if (d->dtype == CODON_BF16) return conv2d_fwd_bf16(d, x, w_packed, y, residual, (hipStream_t)stream);
+  if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
+    return conv2d_fwd_bf16(d, x, w_packed, y, residual, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_fwd: dtype %d", d->dtype);
   return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
                         (hipStream_t)stream);
@@ -123,7 +124,7 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
 
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {
   if (!d || !shape_ok(d->batch, d->height, d->width)) return 0;
-  if (d->dtype == CODON_BF16) return conv_wgrad_bf16_workspace_bytes(d);
+  if (d->dtype == CODON_BF16 || d->dtype == CODON_F16) return conv_wgrad_bf16_workspace_bytes(d);
   return conv_wgrad_workspace_bytes(d);
 }
 
@@ -134,7 +135,7 @@ int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, 
   CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
                     d->y_coff + d->cout <= d->y_ctotal,
                 CODON_ERR_BAD_ARG, "conv2d_wgrad: channel slice outside its buffer");
-  if (d->dtype == CODON_BF16)
+  if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
     return conv2d_wgrad_bf16(d, x, gy, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d", d->dtype);
   return conv2d_wgrad_f32(d, (const float*)x, (const float*)gy, dw, (float*)workspace, workspace_bytes, accumulate,
@@ -146,7 +147,7 @@ int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
   CODON_REQUIRE(x && w_oihw && y, CODON_ERR_BAD_ARG, "stem_fwd: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stem_fwd: bad shape");
   CODON_REQUIRE(y_coff >= 0 && y_coff + 64 <= y_ctotal, CODON_ERR_BAD_ARG, "stem_fwd: output slice outside buffer");
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
   return stem_fwd(batch, height, width, x, w_oihw, y, y_ctotal, y_coff, 1, nullptr, 0, 0, dtype,
                   (hipStream_t)stream);
 }
@@ -156,7 +157,7 @@ int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, 
   CODON_REQUIRE(x && w_oihw && residual && y, CODON_ERR_BAD_ARG, "head_fwd: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "head_fwd: bad shape");
   CODON_REQUIRE(x_coff >= 0 && x_coff + 64 <= x_ctotal, CODON_ERR_BAD_ARG, "head_fwd: input slice outside buffer");
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
   return head_fwd(batch, height, width, x, x_ctotal, x_coff, w_oihw, residual, y, dtype, (hipStream_t)stream);
 }
 
@@ -172,7 +173,7 @@ int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codo
                 "cac_stats_fwd: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_stats_fwd: bad shape");
   CODON_REQUIRE(((uintptr_t)partials % 8) == 0, CODON_ERR_BAD_ARG, "cac_stats_fwd: partials not 8-byte aligned");
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
   return cac_stats_fwd(batch, height, width, pre_c, pre, pooled, partials, dtype, (hipStream_t)stream);
 }
 
@@ -199,7 +200,7 @@ int codon_cac_apply_fwd(int32_t batch, int32_t height, int32_t width, const codo
                     slice_ok(out) && slice_ok(out_c),
                 CODON_ERR_BAD_ARG, "cac_apply_fwd: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_apply_fwd: bad shape");
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_apply_fwd: dtype %d", dtype);
   return cac_apply_fwd(batch, height, width, pre, pre_c, ch, sp, inputs, inputs_c, out, out_c, dtype,
                        (hipStream_t)stream);
 }
@@ -210,7 +211,7 @@ int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const floa
   CODON_REQUIRE(x && w_64x9 && slice_ok(y) && (!mask || slice_ok(mask)), CODON_ERR_BAD_ARG,
                 "stencil_1to64: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stencil_1to64: bad shape");
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "stencil_1to64: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "stencil_1to64: dtype %d", dtype);
   return stem_fwd(batch, height, width, x, w_64x9, y->data, y->ctotal, y->coff, flags, mask ? mask->data : nullptr,
                   mask ? mask->ctotal : 0, mask ? mask->coff : 0, dtype, (hipStream_t)stream);
 }
@@ -223,7 +224,7 @@ size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_
 int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a, const float* s,
                         float* dw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t dtype,
                         codon_stream_t stream) {
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "conv1ch_wgrad: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "conv1ch_wgrad: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(a) && s && dw && workspace, CODON_ERR_BAD_ARG, "conv1ch_wgrad: null pointer or bad slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "conv1ch_wgrad: bad shape");
   return conv1ch_wgrad(batch, height, width, a->data, a->ctotal, a->coff, s, dw, flip, (float*)workspace,
@@ -233,7 +234,7 @@ int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codo
 int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst,
                       const codon_tensor* src, const codon_tensor* mask, int32_t accumulate, int32_t dtype,
                       codon_stream_t stream) {
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "ew_add_mask: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "ew_add_mask: dtype %d", dtype);
   auto ok = [&](const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + channels <= t->ctotal; };
   CODON_REQUIRE(channels > 0 && ok(dst) && (!src || ok(src)) && (!mask || ok(mask)), CODON_ERR_BAD_ARG,
                 "ew_add_mask: null pointer or bad channel slice");
@@ -252,7 +253,7 @@ int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const cod
                          const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
                          const float* ch, const float* sp, const float* pools, float* g_z, float* part_gch,
                          int32_t* part_arg, int32_t dtype, codon_stream_t stream) {
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_bwd_reduce: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_bwd_reduce: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pools &&
                     g_z && part_gch && part_arg,
                 CODON_ERR_BAD_ARG, "cac_bwd_reduce: null pointer or bad channel slice");
@@ -289,7 +290,7 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
                         const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
                         const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
                         int32_t accumulate_in, int32_t dtype, codon_stream_t stream) {
-  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_BF16, CODON_ERR_UNSUPPORTED, "cac_bwd_apply: dtype %d", dtype);
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_bwd_apply: dtype %d", dtype);
   CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && ch && sp && pooled &&
                     g_pooled && g_pools && argpix && slice_ok(g_pre) && slice_ok(g_pre_c) && slice_ok(g_in) &&
                     slice_ok(g_in_c),

@@ -25,7 +25,26 @@
 namespace codon {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+
+// 16-bit element traits: storage is raw 16 bits either way; E picks the MFMA opcode and the conversions
+struct EBf16 {
+  typedef bf16x8 vec8;
+  __device__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  __device__ static float to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
+  __device__ static u16 from_f32(float f) { __bf16 b = (__bf16)f; return *reinterpret_cast<u16*>(&b); }
+  __device__ static float lo(unsigned w) { return __uint_as_float(w << 16); }
+  __device__ static float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+};
+struct EF16 {
+  typedef f16x8 vec8;
+  __device__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  __device__ static float to_f32(u16 v) { return (float)*reinterpret_cast<const _Float16*>(&v); }
+  __device__ static u16 from_f32(float f) { const _Float16 h = (_Float16)f; return *reinterpret_cast<const u16*>(&h); }
+  __device__ static float lo(unsigned w) { return to_f32((u16)(w & 0xffffu)); }
+  __device__ static float hi(unsigned w) { return to_f32((u16)(w >> 16)); }
+};
 
 struct Conv16Params {
   const u16* x;
@@ -46,8 +65,9 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
   return *reinterpret_cast<u16*>(&b);
 }
 
-template <int KS, int CIN, int COUT>
+template <class E, int KS, int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
+  typedef typename E::vec8 vec8;
   constexpr int PAD = KS / 2;
   constexpr int PSEG = 2;
   constexpr int TW = 32, TH = 4 * PSEG;
@@ -160,22 +180,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
     const uint4* wb = ws0 + (s & 1) * WS + half * COUT + l31;
 #pragma unroll
     for (int dx = 0; dx < KS; ++dx) {
-      bf16x8 a[CT], bv[PSEG];
+      vec8 a[CT], bv[PSEG];
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const uint4 v = wb[dx * NCB * COUT + t * 32];
-        a[t] = *reinterpret_cast<const bf16x8*>(&v);
+        a[t] = *reinterpret_cast<const vec8*>(&v);
       }
 #pragma unroll
       for (int i = 0; i < PSEG; ++i) {
         const uint4 v = xb[i * XQ + dx];
-        bv[i] = *reinterpret_cast<const bf16x8*>(&v);
+        bv[i] = *reinterpret_cast<const vec8*>(&v);
       }
 #pragma unroll
       for (int i = 0; i < PSEG; ++i)
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], bv[i], acc[i][t], 0, 0, 0);
+          acc[i][t] = E::mfma(a[t], bv[i], acc[i][t]);
     }
 
     if (has_next) STORE_W((s + 1) & 1);
@@ -207,10 +227,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
             const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[i][t][r];
             if (relu) v = fmaxf(v, 0.f);
-            if (addr) v += bf16_to_f32(rg[co * HW + pix]);
-            if (mask) v = bf16_to_f32(rg[co * HW + pix]) > 0.f ? v : 0.f;
-            if (accum) v += bf16_to_f32(yg[co * HW + pix]);
-            yg[co * HW + pix] = f32_to_bf16(v);
+            if (addr) v += E::to_f32(rg[co * HW + pix]);
+            if (mask) v = E::to_f32(rg[co * HW + pix]) > 0.f ? v : 0.f;
+            if (accum) v += E::to_f32(yg[co * HW + pix]);
+            yg[co * HW + pix] = E::from_f32(v);
           }
         }
       }
@@ -230,8 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
 // touches one full 128-byte line per instruction; outputs / residual / mask are 4-byte accesses likewise.
 // PAIRED = false: tiles are pixels [0,32) and [32,64), 2-byte accesses (any HW).
 constexpr int C1_ITER = 1;  // >1 measured slower (4: 5.4 vs 3.2 ms): the wave is latency-bound, more workgroups hide it better
-template <int CIN, int COUT, bool PAIRED>
+template <class E, int CIN, int COUT, bool PAIRED>
 __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p) {
+  typedef typename E::vec8 vec8;
   constexpr int NKS = CIN / 16, CT = COUT / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -274,11 +295,11 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
 
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    bf16x8 a[CT], bv[2];
+    vec8 a[CT], bv[2];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const uint4 v = wg[(ks * 2 + half) * COUT + t * 32 + l31];
-      a[t] = *reinterpret_cast<const bf16x8*>(&v);
+      a[t] = *reinterpret_cast<const vec8*>(&v);
     }
     if constexpr (PAIRED) {
       const u16* src = xg + (long)(ks * 16 + half * 8) * HW + pp;
@@ -292,8 +313,8 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
         o[j] = (d[2 * j] >> 16) | (d[2 * j + 1] & 0xffff0000u);      // odd pixel
       }
       const uint4 ve = make_uint4(e[0], e[1], e[2], e[3]), vo = make_uint4(o[0], o[1], o[2], o[3]);
-      bv[0] = *reinterpret_cast<const bf16x8*>(&ve);
-      bv[1] = *reinterpret_cast<const bf16x8*>(&vo);
+      bv[0] = *reinterpret_cast<const vec8*>(&ve);
+      bv[1] = *reinterpret_cast<const vec8*>(&vo);
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -306,14 +327,14 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
           w4[j] = lo | (hi << 16);
         }
         const uint4 v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-        bv[i] = *reinterpret_cast<const bf16x8*>(&v);
+        bv[i] = *reinterpret_cast<const vec8*>(&v);
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int t = 0; t < CT; ++t)
-        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], bv[i], acc[i][t], 0, 0, 0);
+        acc[i][t] = E::mfma(a[t], bv[i], acc[i][t]);
   }
 
   if constexpr (PAIRED) {
@@ -327,15 +348,15 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
         if (rg) {
           const unsigned m = *reinterpret_cast<const unsigned*>(rg + co * HW + pp);
-          const float m0 = __uint_as_float(m << 16), m1 = __uint_as_float(m & 0xffff0000u);
+          const float m0 = E::lo(m), m1 = E::hi(m);
           if (addr) { v0 += m0; v1 += m1; }
           if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
         }
         if (accum) {
           const unsigned m = *reinterpret_cast<const unsigned*>(yg + co * HW + pp);
-          v0 += __uint_as_float(m << 16); v1 += __uint_as_float(m & 0xffff0000u);
+          v0 += E::lo(m); v1 += E::hi(m);
         }
-        *reinterpret_cast<unsigned*>(yg + co * HW + pp) = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+        *reinterpret_cast<unsigned*>(yg + co * HW + pp) = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
       }
     }
     }
@@ -350,10 +371,10 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
           const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = acc[i][t][r];
           if (relu) v = fmaxf(v, 0.f);
-          if (addr) v += bf16_to_f32(rg[co * HW + px[i]]);
-          if (mask) v = bf16_to_f32(rg[co * HW + px[i]]) > 0.f ? v : 0.f;
-          if (accum) v += bf16_to_f32(yg[co * HW + px[i]]);
-          yg[co * HW + px[i]] = f32_to_bf16(v);
+          if (addr) v += E::to_f32(rg[co * HW + px[i]]);
+          if (mask) v = E::to_f32(rg[co * HW + px[i]]) > 0.f ? v : 0.f;
+          if (accum) v += E::to_f32(yg[co * HW + px[i]]);
+          yg[co * HW + px[i]] = E::from_f32(v);
         }
       }
     }
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
   }  // it
 }
 
-template <int CIN, int COUT>
+template <class E, int CIN, int COUT>
 static int launch_conv1x1_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
                              hipStream_t stream) {
   Conv16Params p;
@@ -377,13 +398,14 @@ static int launch_conv1x1_16(const codon_conv_desc* d, const void* x, const void
   const bool al4 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                      reinterpret_cast<uintptr_t>(res)) % 4) == 0;
   if (HW % 2 == 0 && al4)
-    hipLaunchKernelGGL((conv1x1_bf16_kernel<CIN, COUT, true>), dim3(gx, d->batch), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv1x1_bf16_kernel<E, CIN, COUT, true>), dim3(gx, d->batch), dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv1x1_bf16_kernel<CIN, COUT, false>), dim3(gx, d->batch), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv1x1_bf16_kernel<E, CIN, COUT, false>), dim3(gx, d->batch), dim3(256), 0, stream, p);
   return check_launch("conv1x1_bf16_kernel");
 }
 
 // OIHW fp32 -> bf16 packed [chunk][dy][dx][cb (2)][cout][8 ch]; DGRAD: flipped taps, in/out swapped.
+template <class E>
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks,
                                         int dgrad) {
   const int kin = dgrad ? cout : cin, kout = dgrad ? cin : cout;
@@ -400,11 +422,11 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __rest
     float v;
     if (!dgrad) v = w[(((long)o * cin + ci) * ks + dy) * ks + dx];
     else v = w[(((long)ci * cin + o) * ks + (ks - 1 - dy)) * ks + (ks - 1 - dx)];
-    out[i] = f32_to_bf16(v);
+    out[i] = E::from_f32(v);
   }
 }
 
-template <int KS, int CIN, int COUT>
+template <class E, int KS, int CIN, int COUT>
 static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
                          hipStream_t stream) {
   Conv16Params p;
@@ -419,32 +441,43 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel");
 }
 
-int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
-                    hipStream_t stream) {
+template <class E>
+static int conv2d_fwd_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                         hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
-    case 5128128: return launch_conv16<5, 128, 128>(d, x, w, y, res, stream);
-    case 5064064: return launch_conv16<5, 64, 64>(d, x, w, y, res, stream);
-    case 3064064: return launch_conv16<3, 64, 64>(d, x, w, y, res, stream);
-    case 3128064: return launch_conv16<3, 128, 64>(d, x, w, y, res, stream);
-    case 3064128: return launch_conv16<3, 64, 128>(d, x, w, y, res, stream);
-    case 1128064: return launch_conv1x1_16<128, 64>(d, x, w, y, res, stream);
-    case 1064128: return launch_conv1x1_16<64, 128>(d, x, w, y, res, stream);
+    case 5128128: return launch_conv16<E, 5, 128, 128>(d, x, w, y, res, stream);
+    case 5064064: return launch_conv16<E, 5, 64, 64>(d, x, w, y, res, stream);
+    case 3064064: return launch_conv16<E, 3, 64, 64>(d, x, w, y, res, stream);
+    case 3128064: return launch_conv16<E, 3, 128, 64>(d, x, w, y, res, stream);
+    case 3064128: return launch_conv16<E, 3, 64, 128>(d, x, w, y, res, stream);
+    case 1128064: return launch_conv1x1_16<E, 128, 64>(d, x, w, y, res, stream);
+    case 1064128: return launch_conv1x1_16<E, 64, 128>(d, x, w, y, res, stream);
     default:
-      set_error("conv2d_fwd: no bf16 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      set_error("conv2d_fwd: no 16-bit kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
       return CODON_ERR_UNSUPPORTED;
   }
 }
 
-int pack_weight_bf16(const float* w, void* out, int cout, int cin, int ks, int mode, hipStream_t stream) {
+int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                    hipStream_t stream) {
+  return d->dtype == CODON_F16 ? conv2d_fwd_16<EF16>(d, x, w, y, res, stream)
+                               : conv2d_fwd_16<EBf16>(d, x, w, y, res, stream);
+}
+
+int pack_weight_bf16(const float* w, void* out, int cout, int cin, int ks, int mode, int dtype, hipStream_t stream) {
   const long n = (long)cout * cin * ks * ks;
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks,
-                     mode == CODON_PACK_DGRAD ? 1 : 0);
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(pack_weight_bf16_kernel<EF16>, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks,
+                       mode == CODON_PACK_DGRAD ? 1 : 0);
+  else
+    hipLaunchKernelGGL(pack_weight_bf16_kernel<EBf16>, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin,
+                       ks, mode == CODON_PACK_DGRAD ? 1 : 0);
   return check_launch("pack_weight_bf16_kernel");
 }
 

@@ -24,6 +24,15 @@
 namespace codon {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct WBf16 {
+  typedef bf16x8 vec8;
+  __device__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct WF16 {
+  typedef f16x8 vec8;
+  __device__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
@@ -36,8 +45,9 @@ struct Wgrad16Params {
   int tiles_x, band_tiles_y, nbands, nsplit;
 };
 
-template <int KS>
+template <class E, int KS>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Params p) {
+  typedef typename E::vec8 vec8;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = 4;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1, NP = XR * XQ;
@@ -157,16 +167,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
 #pragma unroll
       for (int c0 = 0; c0 < TW; c0 += 16) {
         const uint4 av = *reinterpret_cast<const uint4*>(gs + a_lane + (r * TW + c0) * 2);
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&av);
+        const vec8 a = *reinterpret_cast<const vec8*>(&av);
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
           const char* bp = xs + b_lane + tap_off[j] + (r * XQ + c0) * (XROWW * 4);
           typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + 4 * XROWW * 4));
-          union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+          union { struct { s16x4 l, h; } s; vec8 v; } u;
           u.s.l = lo; u.s.h = hi;
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, u.v, acc[j], 0, 0, 0);
+          acc[j] = E::mfma(a, u.v, acc[j]);
         }
       }
     }
@@ -236,9 +246,17 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   p.tiles_x = (d->width + 31) / 32;
   p.band_tiles_y = pl.band_tiles_y; p.nbands = pl.nbands; p.nsplit = pl.nsplit;
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
-  if (d->ksize == 5) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<5>, grid, dim3(512), 0, stream, p);
-  else if (d->ksize == 3) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, grid, dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(512), 0, stream, p);
+  const bool f16 = d->dtype == CODON_F16;
+  if (d->ksize == 5) {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 5>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 5>), grid, dim3(512), 0, stream, p);
+  } else if (d->ksize == 3) {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 3>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 3>), grid, dim3(512), 0, stream, p);
+  } else {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 1>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 1>), grid, dim3(512), 0, stream, p);
+  }
   int st = check_launch("conv_wgrad_bf16_kernel");
   if (st != CODON_OK) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);

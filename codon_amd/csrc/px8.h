@@ -12,7 +12,8 @@
 namespace codon {
 
 constexpr int PX_TILE = 2048;
-typedef unsigned short u16_t;
+typedef unsigned short u16_t;   // bf16 storage
+struct h16_t { unsigned short bits; };   // fp16 storage (distinct C++ type so overloads can tell them apart)
 
 __device__ __forceinline__ float b2f(u16_t v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ u16_t f2b(float f) {
@@ -127,12 +128,91 @@ struct PxB16S {
   }
 };
 
+// 16-bit conversions by storage type
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)*reinterpret_cast<const _Float16*>(&v); }
+__device__ __forceinline__ unsigned short f2h(float f) {
+  const _Float16 h = (_Float16)f;
+  return *reinterpret_cast<const unsigned short*>(&h);
+}
+struct CvtB16 {
+  typedef u16_t T;
+  __device__ static float lo(unsigned w) { return __uint_as_float(w << 16); }
+  __device__ static float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  __device__ static float one(u16_t v) { return b2f(v); }
+  __device__ static unsigned short pack(float f) { return f2b(f); }
+};
+struct CvtH16 {
+  typedef h16_t T;
+  __device__ static float lo(unsigned w) { return h2f((unsigned short)(w & 0xffffu)); }
+  __device__ static float hi(unsigned w) { return h2f((unsigned short)(w >> 16)); }
+  __device__ static float one(h16_t v) { return h2f(v.bits); }
+  __device__ static unsigned short pack(float f) { return f2h(f); }
+};
+
+template <class C>
+struct Px16V {
+  typedef typename C::T T;
+  __device__ static long pix(long tile0, int tid, int i) { return tile0 + tid * 8 + i; }
+  __device__ static void loadf(const float* pl, long tile0, int tid, long HW, float (&v)[8]) {
+    PxB16V::loadf(pl, tile0, tid, HW, v);
+  }
+  __device__ static void storef(float* pl, long tile0, int tid, long HW, const float (&v)[8]) {
+    PxB16V::storef(pl, tile0, tid, HW, v);
+  }
+  __device__ static void load(const T* pl, long tile0, int tid, long HW, float (&v)[8]) {
+    const long p = tile0 + tid * 8;
+    const uint4 q = p < HW ? *reinterpret_cast<const uint4*>(pl + p) : make_uint4(0, 0, 0, 0);
+    v[0] = C::lo(q.x); v[1] = C::hi(q.x); v[2] = C::lo(q.y); v[3] = C::hi(q.y);
+    v[4] = C::lo(q.z); v[5] = C::hi(q.z); v[6] = C::lo(q.w); v[7] = C::hi(q.w);
+  }
+  __device__ static void store(T* pl, long tile0, int tid, long HW, const float (&v)[8]) {
+    const long p = tile0 + tid * 8;
+    if (p < HW) {
+      uint4 q;
+      q.x = (unsigned)C::pack(v[0]) | ((unsigned)C::pack(v[1]) << 16);
+      q.y = (unsigned)C::pack(v[2]) | ((unsigned)C::pack(v[3]) << 16);
+      q.z = (unsigned)C::pack(v[4]) | ((unsigned)C::pack(v[5]) << 16);
+      q.w = (unsigned)C::pack(v[6]) | ((unsigned)C::pack(v[7]) << 16);
+      *reinterpret_cast<uint4*>(pl + p) = q;
+    }
+  }
+};
+template <class C>
+struct Px16S {
+  typedef typename C::T T;
+  __device__ static long pix(long tile0, int tid, int i) { return tile0 + (long)i * 256 + tid; }
+  __device__ static void loadf(const float* pl, long tile0, int tid, long HW, float (&v)[8]) {
+    PxF32S::load(pl, tile0, tid, HW, v);
+  }
+  __device__ static void storef(float* pl, long tile0, int tid, long HW, const float (&v)[8]) {
+    PxF32S::store(pl, tile0, tid, HW, v);
+  }
+  __device__ static void load(const T* pl, long tile0, int tid, long HW, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long p = tile0 + (long)i * 256 + tid;
+      v[i] = p < HW ? C::one(pl[p]) : 0.f;
+    }
+  }
+  __device__ static void store(T* pl, long tile0, int tid, long HW, const float (&v)[8]) {
+    const unsigned short* dummy = nullptr; (void)dummy;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long p = tile0 + (long)i * 256 + tid;
+      if (p < HW) *reinterpret_cast<unsigned short*>(pl + p) = C::pack(v[i]);
+    }
+  }
+};
+
 // Host-side dispatch: calls fn(Policy{}) with the widest policy the shapes/pointers allow.
 template <typename F>
 static inline void px_dispatch(int dtype, long HW, bool aligned16, F&& fn) {
   if (dtype == 1 /* CODON_BF16 */) {
     if (HW % 8 == 0 && aligned16) fn(PxB16V{});
     else fn(PxB16S{});
+  } else if (dtype == 2 /* CODON_F16 */) {
+    if (HW % 8 == 0 && aligned16) fn(Px16V<CvtH16>{});
+    else fn(Px16S<CvtH16>{});
   } else {
     if (HW % 4 == 0 && aligned16) fn(PxF32V{});
     else fn(PxF32S{});

@@ -20,6 +20,18 @@ struct Vec<1> { using T = float; };
 // element accessors: T = float (fp32 activations) or u16_t (bf16 activations); math is always fp32
 __device__ __forceinline__ float ldx(const float* p) { return *p; }
 __device__ __forceinline__ float ldx(const u16_t* p) { return b2f(*p); }
+__device__ __forceinline__ float ldx(const h16_t* p) { return h2f(p->bits); }
+__device__ __forceinline__ void stx(h16_t* p, float v) { p->bits = f2h(v); }
+__device__ __forceinline__ void ld4(const h16_t* p, float (&o)[4]) {
+  const uint2 c = *reinterpret_cast<const uint2*>(p);
+  o[0] = CvtH16::lo(c.x); o[1] = CvtH16::hi(c.x); o[2] = CvtH16::lo(c.y); o[3] = CvtH16::hi(c.y);
+}
+__device__ __forceinline__ void st4(h16_t* p, const float (&o)[4]) {
+  uint2 c;
+  c.x = (unsigned)f2h(o[0]) | ((unsigned)f2h(o[1]) << 16);
+  c.y = (unsigned)f2h(o[2]) | ((unsigned)f2h(o[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = c;
+}
 __device__ __forceinline__ void stx(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stx(u16_t* p, float v) { *p = f2b(v); }
 __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
@@ -197,6 +209,9 @@ int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y
   if (dtype == CODON_BF16)
     return stem_launch<u16_t>(B, H, W, x, w, (u16_t*)y, y_ctotal, y_coff, flags, (const u16_t*)mask, m_ctotal, m_coff,
                               stream);
+  if (dtype == CODON_F16)
+    return stem_launch<h16_t>(B, H, W, x, w, (h16_t*)y, y_ctotal, y_coff, flags, (const h16_t*)mask, m_ctotal, m_coff,
+                              stream);
   return stem_launch<float>(B, H, W, x, w, (float*)y, y_ctotal, y_coff, flags, (const float*)mask, m_ctotal, m_coff,
                             stream);
 }
@@ -222,6 +237,7 @@ static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff
 int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
              int dtype, hipStream_t stream) {
   if (dtype == CODON_BF16) return head_launch<u16_t>(B, H, W, (const u16_t*)x, x_ctotal, x_coff, w, res, y, stream);
+  if (dtype == CODON_F16) return head_launch<h16_t>(B, H, W, (const h16_t*)x, x_ctotal, x_coff, w, res, y, stream);
   return head_launch<float>(B, H, W, (const float*)x, x_ctotal, x_coff, w, res, y, stream);
 }
 
@@ -300,7 +316,10 @@ int conv1ch_wgrad(int B, int H, int W, const void* a, int a_ctotal, int a_coff, 
                 "conv1ch_wgrad: workspace too small");
   const long HW = (long)H * W;
   const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
-  if (dtype == CODON_BF16)
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(conv1ch_wgrad_kernel<h16_t>, dim3(B * nrowblk), dim3(256), 0, stream, (const h16_t*)a,
+                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
+  else if (dtype == CODON_BF16)
     hipLaunchKernelGGL(conv1ch_wgrad_kernel<u16_t>, dim3(B * nrowblk), dim3(256), 0, stream, (const u16_t*)a,
                        a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
   else

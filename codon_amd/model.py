@@ -120,16 +120,15 @@ class _CODONBase(nn.Module):
         """Activation / MFMA operand dtype: None = follow the parameters' dtype; torch.bfloat16 with fp32
         parameters = bf16 activations and packed weights, fp32 accumulate, fp32 master weights
         (BASELINE.json configs[2], [4]).  Inputs and the output stay fp32 1-channel maps."""
-        if dtype not in (None, torch.float32, torch.bfloat16):
-            raise NotImplementedError(f"codon_amd.CODONNet: compute dtype {dtype} not supported (fp32, bf16)")
+        if dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"codon_amd.CODONNet: compute dtype {dtype} not supported (fp32, bf16, fp16)")
         self.compute_dtype = dtype
         return self
 
     def _act_dtype(self) -> torch.dtype:
         dt = self.compute_dtype or self.input.weight.dtype
-        if dt not in (torch.float32, torch.bfloat16):
-            raise NotImplementedError(f"codon_amd.CODONNet: dtype {dt} not supported (fp32 and bf16 only; the "
-                                      "reference's .half() inference has no kernel here and there is no fallback)")
+        if dt not in (torch.float32, torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"codon_amd.CODONNet: dtype {dt} not supported (fp32, bf16, fp16)")
         return dt
 
     # -- packed weights -------------------------------------------------------------------
@@ -163,10 +162,13 @@ class _CODONBase(nn.Module):
             raise RuntimeError("codon_amd.CODONNet runs on MI355X only: move the module and inputs to 'cuda' "
                                "(there is no CPU fallback)")
         adt = self._act_dtype()
-        if x.dtype not in (torch.float32, torch.bfloat16) or y.dtype != x.dtype:
-            raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16)")
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or y.dtype != x.dtype:
+            raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16, fp16)")
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
+            if adt == torch.float16:
+                raise NotImplementedError("codon_amd.CODONNet: fp16 is inference-only (as in the reference, "
+                                          "test.py:52); train in fp32 or bf16, or call under torch.no_grad()")
             from .autograd import codon_apply  # training path (custom backward)
             return codon_apply(self, x, y)
         out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)

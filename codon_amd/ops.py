@@ -15,7 +15,12 @@ def _dt(t: torch.Tensor) -> int:
         return L.F32
     if t.dtype == torch.bfloat16:
         return L.BF16
-    raise TypeError(f"codon_amd: unsupported dtype {t.dtype} (fp32 and bf16 only)")
+    if t.dtype == torch.float16:
+        return L.F16
+    raise TypeError(f"codon_amd: unsupported dtype {t.dtype} (fp32, bf16, fp16)")
+
+
+_DT_CODE = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
 
 
 def _dev(*ts):
@@ -77,8 +82,7 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
     dtype = dtype or torch.float32
     out = torch.empty(w.numel(), dtype=dtype, device=dev)
     with torch.cuda.device(dev):
-        L.check(lib.codon_conv_pack_weight(_ptr(w), _ptr(out), cout, cin, k, mode,
-                                           L.F32 if dtype == torch.float32 else L.BF16, _stream(dev)),
+        L.check(lib.codon_conv_pack_weight(_ptr(w), _ptr(out), cout, cin, k, mode, _DT_CODE[dtype], _stream(dev)),
                 "conv_pack_weight")
     return out
 

@@ -7,7 +7,7 @@
  * function returns CODON_OK (0) or a negative codon_status; codon_last_error_string() gives
  * the detail for the calling thread.
  *
- * Activation layout: NCHW, contiguous, fp32 (CODON_F32) or bf16 (CODON_BF16).  A tensor
+ * Activation layout: NCHW, contiguous, fp32 (CODON_F32), bf16 (CODON_BF16) or fp16 (CODON_F16).  A tensor
  * argument may be a channel slice of a wider buffer: (ctotal, coff) describe a buffer of
  * shape (B, ctotal, H, W) of which channels [coff, coff+C) are read/written -- this is how
  * the torch.cat calls of the reference (CODON_x4.py:79,80,85,119,125) disappear.
@@ -33,7 +33,10 @@ typedef enum codon_status {
   CODON_ERR_LAUNCH = -3       /* HIP reported a launch failure */
 } codon_status;
 
-typedef enum codon_dtype { CODON_F32 = 0, CODON_BF16 = 1 } codon_dtype;
+/* dtype of the 64/128-channel activations (and of the packed conv weights): storage + MFMA operand type;
+ * accumulation is always fp32.  CODON_F16 is the reference script's own inference precision
+ * (model.cuda().half(), /root/reference/CODON_X4/test.py:52,122-123). */
+typedef enum codon_dtype { CODON_F32 = 0, CODON_BF16 = 1, CODON_F16 = 2 } codon_dtype;
 
 enum {
   CODON_CONV_RELU = 1,         /* y = max(conv, 0)          (self.relu(self.convN(..)))      */

@@ -137,3 +137,17 @@ def test_forward_bf16_random_128():
     with torch.no_grad():
         o = m(x.cuda(), y.cuda())
     assert rel_rmse(o.cpu(), ref) <= 3e-2
+
+
+# ---- fp16: the reference script's own inference precision (model.cuda().half(), test.py:52,122-123) -------
+@pytest.mark.parametrize("name", ["he0_x4_2x24x20_taps", "kat0_x4_2x32x24", "he0_x16_1x33x9", "kat0_x4_1x1x1"])
+def test_forward_half_like_reference_script(name):
+    z, variant, sd, x, y = load_case(name)
+    m = _model(variant, sd).half()                      # exactly what test.py does
+    with torch.no_grad():
+        o = m(x.cuda().half(), y.cuda().half())
+    assert o.dtype == torch.float16 and o.shape == x.shape
+    # fp16 has 11 significand bits: ~8x tighter than bf16
+    assert rel_rmse(o.float().cpu(), z["out_fp64"]) <= 6e-3
+    with pytest.raises(NotImplementedError):
+        m(x.cuda().half(), y.cuda().half())             # grad-enabled fp16 is refused, not silently wrong

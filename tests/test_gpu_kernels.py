@@ -320,3 +320,18 @@ def test_conv2d_wgrad_bf16_slices():
     dw = torch.empty((64, 64, 5, 5), device=dev)
     ops.conv2d_wgrad(Slice(xb.to(dev), 64, 64), Slice(gb.to(dev), 0, 64), dw, 5)
     assert rel_rmse(dw.cpu(), w.grad) < 1e-5
+
+
+@pytest.mark.parametrize("k,cin,cout", [(5, 128, 128), (3, 64, 64), (1, 128, 64)])
+def test_conv2d_fp16_vs_torch(k, cin, cout):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 19, 46
+    x = _rand((B, cin, H, W), 1).half()
+    w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5)
+    ref = F.conv2d(x.float(), w.half().float(), None, 1, k // 2)
+    wp = ops.packed_weight(w.to(dev), dtype=torch.float16)
+    y = torch.full((B, cout, H, W), float("nan"), device=dev, dtype=torch.float16)
+    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, relu=True)
+    assert rel_rmse(y.float().cpu(), F.relu(ref)) < 5e-4
