@@ -61,6 +61,12 @@ SIGNATURES = {
     "codon_cac_bwd_spatial": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "codon_cac_bwd_apply": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _TP, _TP, _TP, _TP,
                                       _I, _I, _P]),
+    "codon_postprocess_u8": (C.c_int, [C.c_int64, _P, _P, _P]),
+    "codon_masked_sqerr": (C.c_int, [C.c_int64, _P, _P, _P, _P]),
+    "codon_ssim_tiles": (_I, [_I, _I, _I]),
+    "codon_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "codon_l1_fwd": (C.c_int, [C.c_int64, _P, _P, _P, _I, _P, _P]),
+    "codon_ssim_l1_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "codon_bicubic_upsample": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
 }

@@ -9,3 +9,4 @@ if _root not in _sys.path:
 
 from codon_amd.model import CODONNet16 as CODONNet  # noqa: E402,F401
 from codon_amd.model import CAC_channel as CHANNEL, CAC_spatial as SPATIAL  # noqa: E402,F401
+from codon_amd.model import BaseNet_RMCR_fuseRMCR  # noqa: E402,F401  (ablation class of the same file, :16-90)

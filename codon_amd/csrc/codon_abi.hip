@@ -63,6 +63,13 @@ int cac_apply_fwd(int, int, int, const codon_tensor*, const codon_tensor*, const
 
 int bicubic_upsample(int, int, int, int, const float*, const float*, float*, hipStream_t);
 
+int postprocess_u8(const float*, unsigned char*, long, hipStream_t);
+int masked_sqerr(const unsigned char*, const unsigned char*, long, unsigned long long*, hipStream_t);
+int ssim_tiles(int, int, int);
+int ssim_fwd(int, int, int, const float*, const float*, float*, float*, double*, hipStream_t);
+int l1_fwd(long, const float*, const float*, float*, int, double*, hipStream_t);
+int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*, float*, float, float, hipStream_t);
+
 static bool slice_ok(const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + 64 <= t->ctotal; }
 
 static bool shape_ok(int b, int h, int w) { return b > 0 && h > 0 && w > 0 && (long)h * w < (1L << 31); }
@@ -298,6 +305,42 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_apply: bad shape");
   return cac_bwd_apply(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pooled, g_pooled, g_pools, argpix,
                        g_pre, g_pre_c, g_in, g_in_c, accumulate_in, dtype, (hipStream_t)stream);
+}
+
+int codon_postprocess_u8(int64_t n, const float* x, uint8_t* out, codon_stream_t stream) {
+  CODON_REQUIRE(x && out && n > 0, CODON_ERR_BAD_ARG, "postprocess_u8: null pointer or n <= 0");
+  return postprocess_u8(x, out, (long)n, (hipStream_t)stream);
+}
+
+int codon_masked_sqerr(int64_t n, const uint8_t* label, const uint8_t* out, uint64_t* acc, codon_stream_t stream) {
+  CODON_REQUIRE(label && out && acc && n > 0, CODON_ERR_BAD_ARG, "masked_sqerr: null pointer or n <= 0");
+  return masked_sqerr(label, out, (long)n, (unsigned long long*)acc, (hipStream_t)stream);
+}
+
+int32_t codon_ssim_tiles(int32_t batch, int32_t height, int32_t width) {
+  return shape_ok(batch, height, width) ? ssim_tiles(batch, height, width) : 0;
+}
+
+int codon_ssim_fwd(int32_t batch, int32_t height, int32_t width, const float* a, const float* b, float* partial,
+                   float* dmaps, double* value, codon_stream_t stream) {
+  CODON_REQUIRE(a && b && partial && value, CODON_ERR_BAD_ARG, "ssim_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ssim_fwd: bad shape");
+  return ssim_fwd(batch, height, width, a, b, partial, dmaps, value, (hipStream_t)stream);
+}
+
+int codon_l1_fwd(int64_t n, const float* a, const float* b, float* partial, int32_t nparts, double* value,
+                 codon_stream_t stream) {
+  CODON_REQUIRE(a && b && partial && value && n > 0 && nparts > 0, CODON_ERR_BAD_ARG, "l1_fwd: bad argument");
+  return l1_fwd((long)n, a, b, partial, nparts, value, (hipStream_t)stream);
+}
+
+int codon_ssim_l1_bwd(int32_t batch, int32_t height, int32_t width, const float* a, const float* b,
+                      const float* dmaps, float* tmp, float* ga, float ssim_scale, float l1_scale,
+                      codon_stream_t stream) {
+  CODON_REQUIRE(a && b && dmaps && tmp && ga, CODON_ERR_BAD_ARG, "ssim_l1_bwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width) && height >= 7 && width >= 7, CODON_ERR_UNSUPPORTED,
+                "ssim_l1_bwd: needs H, W >= 7 (got %dx%d)", height, width);
+  return ssim_l1_bwd(batch, height, width, a, b, dmaps, tmp, ga, ssim_scale, l1_scale, (hipStream_t)stream);
 }
 
 int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, int32_t scale, const float* lr,

@@ -1,0 +1,268 @@
+// "Next" rows of SURVEY.md 8(f): what sits either side of the network in the reference's script.
+//   postprocess : out = uint8(clip(x,0,1) * 255)   (truncating cast)        CODON_X4/test.py:127-132
+//   masked RMSE : sqrt(sum_{label != 0} (label - out)^2 / #{label != 0})    CODON_X4/test.py:148-164
+//   SSIM        : ssim_exact(img1, img2, sd=1.5)                             CODON_X4/ssim_2.py:36-52
+//                 (scipy gaussian_filter: 13 taps, truncate 4.0, 'reflect' = half-sample symmetric boundary)
+//   L1 + SSIM loss forward/backward for the fwd+bwd config (no loss exists in the reference, SURVEY D8: the
+//   combination is this repo's definition; the SSIM VALUE is pinned to ssim_exact).
+// All of it is 1-channel work (B,1,H,W): a few MB, HBM-trivial; byte/integer pieces are bit-exact.
+
+#include <math.h>
+
+#include "codon_common.h"
+
+namespace codon {
+
+// ---- post-processing ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void postprocess_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ o,
+                                                             long n) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  v = fminf(fmaxf(v, 0.f), 1.f);            // np.clip(out, 0, 1)
+  // (out * 255).astype(np.uint8): the product is computed in the array's dtype, then truncated toward zero
+  o[i] = (unsigned char)(int)(v * 255.f);
+}
+
+// sum of squared integer differences and count of valid pixels: exact in 64-bit integers, so the result is
+// independent of summation order and equals the reference's float64 loop bit for bit.
+__global__ __launch_bounds__(256) void masked_sqerr_kernel(const unsigned char* __restrict__ label,
+                                                           const unsigned char* __restrict__ out, long n,
+                                                           unsigned long long* __restrict__ acc /* [2] */) {
+  unsigned long long s = 0, c = 0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int l = label[i];
+    if (l != 0) {
+      const int d = l - (int)out[i];
+      s += (unsigned long long)(d * d);
+      c += 1;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s += __shfl_xor(s, m, 64);
+    c += __shfl_xor(c, m, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&acc[0], s);
+    atomicAdd(&acc[1], c);
+  }
+}
+
+// ---- SSIM ----------------------------------------------------------------------------------------------
+constexpr int SS_R = 6, SS_T = 32, SS_P = SS_T + 2 * SS_R;  // radius, tile, padded tile
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // scipy 'reflect': (d c b a | a b c d | d c b a)
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -1 - i;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return i;
+}
+
+struct GaussW { float w[2 * SS_R + 1]; };
+
+// One 32x32 output tile per workgroup.  Writes per-tile partial sums of the SSIM map and, if dmaps != null,
+// the three derivative maps d(sum ssim)/d{mu1, s11, s12} (s11 = G(x^2), s12 = G(x*t)) for the backward.
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ partial, float* __restrict__ dmaps,
+                                                       int H, int W, int tiles_x, int tiles_y, GaussW g, float C1,
+                                                       float C2) {
+  __shared__ float ta[SS_P][SS_P + 1], tb[SS_P][SS_P + 1];
+  __shared__ float hz[5][SS_P][SS_T + 1];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, img = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * SS_T, y0 = ty * SS_T;
+  const float* pa = a + (long)img * H * W;
+  const float* pb = b + (long)img * H * W;
+  for (int e = tid; e < SS_P * SS_P; e += 256) {
+    const int r = e / SS_P, c = e % SS_P;
+    const int yy = reflect_idx(y0 + r - SS_R, H), xx = reflect_idx(x0 + c - SS_R, W);
+    ta[r][c] = pa[(long)yy * W + xx];
+    tb[r][c] = pb[(long)yy * W + xx];
+  }
+  __syncthreads();
+  // variances / covariance are shift invariant: take the moments of (a - ca), (b - cb) with ca, cb the tile's
+  // centre pixels, so that E[x^2] - E[x]^2 does not cancel 4+ digits in fp32 on flat image regions
+  const float ca = ta[SS_P / 2][SS_P / 2], cb = tb[SS_P / 2][SS_P / 2];
+  for (int e = tid; e < SS_P * SS_T; e += 256) {   // horizontal pass of the 5 moments
+    const int r = e / SS_T, c = e % SS_T;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+    for (int k = 0; k <= 2 * SS_R; ++k) {
+      const float u = ta[r][c + k] - ca, v = tb[r][c + k] - cb, w = g.w[k];
+      s0 = fmaf(w, u, s0); s1 = fmaf(w, v, s1); s2 = fmaf(w, u * u, s2); s3 = fmaf(w, v * v, s3);
+      s4 = fmaf(w, u * v, s4);
+    }
+    hz[0][r][c] = s0; hz[1][r][c] = s1; hz[2][r][c] = s2; hz[3][r][c] = s3; hz[4][r][c] = s4;
+  }
+  __syncthreads();
+  float local = 0.f;
+  for (int e = tid; e < SS_T * SS_T; e += 256) {
+    const int r = e / SS_T, c = e % SS_T;
+    const int gy = y0 + r, gx = x0 + c;
+    float m[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k <= 2 * SS_R; ++k) {
+      const float w = g.w[k];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) m[q] = fmaf(w, hz[q][r + k][c], m[q]);
+    }
+    if (gy < H && gx < W) {
+      const float mu1 = m[0] + ca, mu2 = m[1] + cb;
+      const float s1 = m[2] - m[0] * m[0], s2 = m[3] - m[1] * m[1], s12 = m[4] - m[0] * m[1];
+      const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
+      const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+      const float ssim = (A1 * A2) / (B1 * B2);
+      local += ssim;
+      if (dmaps) {
+        // S = A1*A2/(B1*B2) with s1 = s11 - mu1^2, s12 = s12raw - mu1*mu2
+        const float inv = 1.f / (B1 * B2);
+        const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -ssim / B1, dB2 = -ssim / B2;
+        const float d_s11 = dB2;                       // via s1
+        const float d_s12 = 2.f * dA2;                 // via A2
+        const float d_mu1 = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 + dA2 * (-2.f * mu2) + dB2 * (-2.f * mu1);
+        const long o = (long)img * 3 * H * W + (long)gy * W + gx;
+        dmaps[o] = d_mu1;
+        dmaps[o + (long)H * W] = d_s11;
+        dmaps[o + 2L * H * W] = d_s12;
+      }
+    }
+  }
+#pragma unroll
+  for (int mm = 32; mm >= 1; mm >>= 1) local += __shfl_xor(local, mm, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// adjoint of the reflect-boundary separable Gaussian applied to the three derivative maps, combined into
+// dL/da = scale * ( G^T(d_mu1) + 2 a G^T(d_s11) + b G^T(d_s12) ) [+ l1_scale * sign(a - b)]
+// G^T along one axis: g[j] = C[j] + C[-1-j] (j <= R-1) + C[2n-1-j] (j >= n-R), C[m] = sum_k w[k] D0[m-k+R], D0 = 0 outside.
+__device__ __forceinline__ float adj_tap(const float* __restrict__ d, int n, int stride, int m, const GaussW& g) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k <= 2 * SS_R; ++k) {
+    const int i = m - k + SS_R;
+    if (i >= 0 && i < n) s = fmaf(g.w[k], d[(long)i * stride], s);
+  }
+  return s;
+}
+__device__ __forceinline__ float adj_axis(const float* __restrict__ d, int n, int stride, int j, const GaussW& g) {
+  float s = adj_tap(d, n, stride, j, g);
+  if (j <= SS_R - 1) s += adj_tap(d, n, stride, -1 - j, g);
+  if (j >= n - SS_R) s += adj_tap(d, n, stride, 2 * n - 1 - j, g);
+  return s;
+}
+
+// pass 1: rows (along W) of each derivative map -> tmp; pass 2: columns + combine.
+__global__ __launch_bounds__(256) void gauss_adj_rows_kernel(const float* __restrict__ d, float* __restrict__ tmp, int H,
+                                                             int W, long total, GaussW g) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;  // over (plane, y, x)
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const long row = idx / W;
+  tmp[idx] = adj_axis(d + row * W, W, 1, x, g);
+}
+__global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(const float* __restrict__ tmp, const float* __restrict__ a,
+                                                          const float* __restrict__ b, float* __restrict__ ga, int H,
+                                                          int W, long total, GaussW g, float ssim_scale,
+                                                          float l1_scale) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;  // over (img, y, x)
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const long t = idx / W;
+  const int y = (int)(t % H);
+  const long img = t / H;
+  const long HW = (long)H * W;
+  const float* base = tmp + img * 3 * HW + x;
+  const float g_mu = adj_axis(base, H, W, y, g);
+  const float g_s11 = adj_axis(base + HW, H, W, y, g);
+  const float g_s12 = adj_axis(base + 2 * HW, H, W, y, g);
+  const float av = a[idx], bv = b[idx];
+  float r = ssim_scale * (g_mu + 2.f * av * g_s11 + bv * g_s12);
+  const float df = av - bv;
+  r += l1_scale * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+  ga[idx] = r;
+}
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ partial, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = sum_i partial[i] in double, fixed order (single thread: a few thousand terms)
+__global__ void sum_partials_f64_kernel(const float* __restrict__ partial, int n, double scale, double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)partial[i];
+  out[0] = s * scale;
+}
+
+static GaussW make_gauss(double sd) {
+  GaussW g;
+  double w[2 * SS_R + 1], sum = 0.0;
+  for (int k = -SS_R; k <= SS_R; ++k) { w[k + SS_R] = exp(-0.5 * k * k / (sd * sd)); sum += w[k + SS_R]; }
+  for (int k = 0; k <= 2 * SS_R; ++k) g.w[k] = (float)(w[k] / sum);
+  return g;
+}
+
+int postprocess_u8(const float* x, unsigned char* o, long n, hipStream_t stream) {
+  hipLaunchKernelGGL(postprocess_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, o, n);
+  return check_launch("postprocess_u8_kernel");
+}
+
+int masked_sqerr(const unsigned char* label, const unsigned char* out, long n, unsigned long long* acc,
+                 hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) { set_error("masked_rmse: memset: %s", hipGetErrorString(e)); return CODON_ERR_LAUNCH; }
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(blocks), dim3(256), 0, stream, label, out, n, acc);
+  return check_launch("masked_sqerr_kernel");
+}
+
+int ssim_tiles(int B, int H, int W) { return B * ((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T); }
+
+int ssim_fwd(int B, int H, int W, const float* a, const float* b, float* partial, float* dmaps, double* value,
+             hipStream_t stream) {
+  const int tx = (W + SS_T - 1) / SS_T, ty = (H + SS_T - 1) / SS_T;
+  const int nt = B * tx * ty;
+  const GaussW g = make_gauss(1.5);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(nt), dim3(256), 0, stream, a, b, partial, dmaps, H, W, tx, ty, g,
+                     0.01f * 0.01f, 0.03f * 0.03f);
+  int st = check_launch("ssim_fwd_kernel");
+  if (st != CODON_OK) return st;
+  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(1), 0, stream, partial, nt, 1.0 / ((double)B * H * W),
+                     value);
+  return check_launch("sum_partials_f64_kernel");
+}
+
+int l1_fwd(long n, const float* a, const float* b, float* partial, int nparts, double* value, hipStream_t stream) {
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nparts), dim3(256), 0, stream, a, b, partial, n);
+  int st = check_launch("l1_partial_kernel");
+  if (st != CODON_OK) return st;
+  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(1), 0, stream, partial, nparts, 1.0 / (double)n, value);
+  return check_launch("sum_partials_f64_kernel");
+}
+
+int ssim_l1_bwd(int B, int H, int W, const float* a, const float* b, const float* dmaps, float* tmp, float* ga,
+                float ssim_scale, float l1_scale, hipStream_t stream) {
+  const GaussW g = make_gauss(1.5);
+  const long t3 = (long)B * 3 * H * W, t1 = (long)B * H * W;
+  hipLaunchKernelGGL(gauss_adj_rows_kernel, dim3((unsigned)((t3 + 255) / 256)), dim3(256), 0, stream, dmaps, tmp, H, W,
+                     t3, g);
+  int st = check_launch("gauss_adj_rows_kernel");
+  if (st != CODON_OK) return st;
+  hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, stream, tmp, a, b, ga, H, W,
+                     t1, g, ssim_scale, l1_scale);
+  return check_launch("ssim_l1_bwd_kernel");
+}
+
+}  // namespace codon

@@ -274,6 +274,70 @@ class CODONNet16(_CODONBase):
     _HAS_UNUSED_GATE5 = False
 
 
+class BaseNet_RMCR_fuseRMCR(nn.Module):
+    """Conv-only ablation of the paper (no CAC gates, the two streams never interact before conv7):
+    /root/reference/CODON_X16/CODON_x16.py:16-90.  Same 19 bias-free convs, same kernels; inference only."""
+
+    def __init__(self):
+        super().__init__()
+        for name, ci, co, k in _MAIN_CONVS:
+            setattr(self, name, Conv2dParams(ci, co, k, he_init=True))
+        self.relu = nn.ReLU()
+        self._pack_cache: Dict[str, tuple] = {}
+        self.compute_dtype: Optional[torch.dtype] = None
+
+    set_compute_dtype = _CODONBase.set_compute_dtype
+    _act_dtype = _CODONBase._act_dtype
+    _packed = _CODONBase._packed
+    __getstate__ = _CODONBase.__getstate__
+
+    def forward(self, x, y):
+        if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"expects two (B,1,H,W) tensors, got {tuple(x.shape)} and {tuple(y.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("codon_amd runs on MI355X only (there is no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("BaseNet_RMCR_fuseRMCR: inference only; call under torch.no_grad()")
+        idt = x.dtype
+        x, y = x.float().contiguous(), y.float().contiguous()
+        B, _, H, W = x.shape
+        adt = self._act_dtype()
+        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=x.device)
+        f32 = lambda t: t if t.dtype == torch.float32 else t.float()
+        P = self._packed
+        t64, stage, r2, oc = new(64), new(128), new(128), new(128)
+
+        def stream(img, w_in, n_ci, c3x3, c5x5, first5, n3, nconf, out_slice):      # :53-74
+            inputs = new(64)
+            ops.stem(img, f32(getattr(self, w_in).weight), Slice(t64))
+            ops.conv2d(Slice(t64), P(n_ci), Slice(inputs), 3, relu=True)
+            cur = Slice(inputs)
+            for i in range(5):
+                a, b = (c5x5, c3x3) if first5 else (c3x3, c5x5)
+                ops.conv2d(cur, P(a), Slice(stage, 0, 64), 5 if first5 else 3, relu=True)
+                ops.conv2d(cur, P(b), Slice(stage, 64, 64), 3 if first5 else 5, relu=True)
+                ops.conv2d(Slice(stage), P(n3), Slice(r2), 5, relu=True)
+                dst = out_slice if i == 4 else Slice(new(64))
+                ops.conv2d(Slice(r2), P(nconf), dst, 1, residual=Slice(inputs))     # confuse(...) + inputs
+                cur = dst
+
+        stream(x, "input", "conv_input", "conv1", "conv2", False, "conv3", "confuse", Slice(oc, 0, 64))
+        stream(y, "input_c", "conv_input_c", "conv5", "conv4", True, "conv6", "confuse_c", Slice(oc, 64, 64))
+        fuse, fA = new(64), new(64)
+        ops.conv2d(Slice(oc), P("conv7"), Slice(fuse), 3, relu=True)                # :76-77
+        f = fuse
+        for _ in range(3):                                                          # :79-85
+            ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True)
+            ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True)
+            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True)
+            ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))
+            f = fA
+        ops.conv2d(Slice(f), P("conv11"), Slice(t64), 3, relu=True)                 # :87
+        out = torch.empty_like(x)
+        ops.head(Slice(t64), f32(self.output.weight), x, out)                       # :88-89
+        return out if idt == torch.float32 else out.to(idt)
+
+
 def strip_module_prefix(state_dict):
     """x16 checkpoints are saved from nn.DataParallel (CODON_X16/test.py:52,60): keys carry 'module.'."""
     return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}

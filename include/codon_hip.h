@@ -195,6 +195,27 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
                         const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
                         int32_t accumulate_in, int32_t dtype, codon_stream_t stream);
 
+/* ---- either side of the network in the reference's script ----------------------------
+ * postprocess_u8 : out[i] = (uint8)(clip(x[i],0,1) * 255)  (truncating)      CODON_X4/test.py:127-132
+ * masked_sqerr   : acc[0] = sum_{label!=0} (label-out)^2, acc[1] = #{label!=0}, exact 64-bit integers;
+ *                  RMSE = sqrt(acc[0]/acc[1])                                 CODON_X4/test.py:148-164
+ * ssim_fwd       : value[0] (double) = mean SSIM map of (a, b), both (B,1,H,W) fp32; 13-tap Gaussian sd 1.5,
+ *                  'reflect' boundary, C1 = 0.01^2, C2 = 0.03^2              CODON_X4/ssim_2.py:36-52
+ *                  partial: codon_ssim_tiles(B,H,W) floats scratch; dmaps: NULL or (B,3,H,W) derivative maps
+ * l1_fwd         : value[0] (double) = mean |a - b| ; partial: nparts floats scratch
+ * ssim_l1_bwd    : ga = ssim_scale * d(sum SSIM)/da + l1_scale * sign(a - b); tmp: (B,3,H,W) scratch; H,W >= 7 */
+int codon_postprocess_u8(int64_t n, const float* x, uint8_t* out, codon_stream_t stream);
+int codon_masked_sqerr(int64_t n, const uint8_t* label, const uint8_t* out, uint64_t* acc,
+                       codon_stream_t stream);
+int32_t codon_ssim_tiles(int32_t batch, int32_t height, int32_t width);
+int codon_ssim_fwd(int32_t batch, int32_t height, int32_t width, const float* a, const float* b,
+                   float* partial, float* dmaps, double* value, codon_stream_t stream);
+int codon_l1_fwd(int64_t n, const float* a, const float* b, float* partial, int32_t nparts,
+                 double* value, codon_stream_t stream);
+int codon_ssim_l1_bwd(int32_t batch, int32_t height, int32_t width, const float* a, const float* b,
+                      const float* dmaps, float* tmp, float* ga, float ssim_scale, float l1_scale,
+                      codon_stream_t stream);
+
 /* ---- synthetic-input generator: x4 / x8 / x16 bicubic upsample ---------------------------------
  * No reference counterpart (the reference's depth inputs are upsampled offline,
  * CODON_X4/test.py:70-77); defined in codon_amd/csrc/upsample.hip, restated in

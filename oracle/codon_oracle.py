@@ -210,6 +210,29 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
     return _conv(out, w("output")) + residual                     # :130-132
 
 
+def forward_rmcr(sd, x, y):
+    """BaseNet_RMCR_fuseRMCR.forward, /root/reference/CODON_X16/CODON_x16.py:51-90 (conv-only ablation)."""
+    r = F.relu
+    w = lambda k: sd[k + ".weight"]
+
+    def stream(img, n_in, n_ci, a, b, n3, nconf):
+        inputs = r(_conv(r(_conv(img, w(n_in))), w(n_ci)))
+        out = inputs
+        for _ in range(5):
+            st = torch.cat((r(_conv(out, w(a))), r(_conv(out, w(b)))), 1)
+            out = _conv(r(_conv(st, w(n3))), w(nconf)) + inputs
+        return out
+
+    out = stream(x, "input", "conv_input", "conv1", "conv2", "conv3", "confuse")          # :53-62
+    out_c = stream(y, "input_c", "conv_input_c", "conv4", "conv5", "conv6", "confuse_c")  # :64-74
+    fuse = r(_conv(torch.cat((out, out_c), 1), w("conv7")))
+    f = fuse
+    for _ in range(3):
+        st = torch.cat((r(_conv(f, w("conv8"))), r(_conv(f, w("conv9")))), 1)
+        f = _conv(r(_conv(st, w("conv10"))), w("confuse_fuse")) + fuse
+    return _conv(r(_conv(f, w("conv11"))), w("output")) + x
+
+
 def forward_numpy(sd, x, y):
     with torch.no_grad():
         return forward(sd, torch.as_tensor(x), torch.as_tensor(y)).numpy()

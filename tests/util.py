@@ -9,7 +9,8 @@ from oracle import codon_oracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz"))
+# network fixtures (tools/make_golden.py); metrics_crops.npz and rmcr_kat0.npz have their own tests
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.split("_")[0] in ("kat0", "he0", "he1"))
 
 
 def load_case(name):
