@@ -128,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
     const u16* src_ = xg + (long)(chunk_) * CK * HW;                                    \
     _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                    \
       const bool m_ = (xmask >> k) & 1u;                                                \
-      const unsigned lo_ = m_ ? src_[xoff[k]] : 0u;                                     \
-      const unsigned hi_ = m_ ? src_[xoff[k] + HW] : 0u;                                \
-      xr[k] = lo_ | (hi_ << 16);                                                        \
+      /* unconditional loads (xoff = 0, in bounds, when masked): a select, not a branch + wait per load */ \
+      const unsigned lo_ = src_[xoff[k]];                                               \
+      const unsigned hi_ = src_[xoff[k] + HW];                                          \
+      xr[k] = m_ ? (lo_ | (hi_ << 16)) : 0u;                                            \
     }                                                                                   \
   }
 #define STORE_X(buf_)                                                                   \

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   {                                                                                \
     const float* src_ = xg + (long)(chunk_) * CK * HW;                             \
     _Pragma("unroll") for (int k = 0; k < XE; ++k)                                 \
-        xr[k] = ((xmask >> k) & 1u) ? src_[xoff[k]] : 0.f;                         \
+        { const float v_ = src_[xoff[k]];  /* unconditional: xoff = 0 (in bounds) when masked */ \
+          xr[k] = ((xmask >> k) & 1u) ? v_ : 0.f; }                                \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \

@@ -113,9 +113,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
       const int r = pi / XQ, qq = pi - r * XQ;
       const int gy_ = ty0 + r - PAD, gx_ = tx0 + qq - PAD;
       const bool ok = e < XWORDS && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
-      const long o = (long)(2 * cp) * HW + (long)gy_ * W + gx_;
-      const unsigned lo = ok ? xg[o] : 0u, hi = ok ? xg[o + HW] : 0u;
-      xr[k] = lo | (hi << 16);
+      const long o = ok ? (long)(2 * cp) * HW + (long)gy_ * W + gx_ : 0;   // clamped: unconditional loads
+      const unsigned lo = xg[o], hi = xg[o + HW];
+      xr[k] = ok ? (lo | (hi << 16)) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < GE; ++k) {
@@ -125,9 +125,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
       const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
       const int gy_ = ty0 + r, gx_ = tx0 + q2;
       const bool rok = gy_ < H;
+      const bool ok0 = rok && gx_ < W, ok1 = rok && gx_ + 1 < W;
       const long o = (long)c * HW + (long)gy_ * W + gx_;
-      const unsigned lo = (rok && gx_ < W) ? gg[o] : 0u, hi = (rok && gx_ + 1 < W) ? gg[o + 1] : 0u;
-      gr[k] = lo | (hi << 16);
+      const unsigned lo = gg[ok0 ? o : 0], hi = gg[ok1 ? o + 1 : 0];
+      gr[k] = (ok0 ? lo : 0u) | ((ok1 ? hi : 0u) << 16);
     }
   };
   auto store_tile = [&](int buf) {
@@ -162,24 +163,44 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
 
     const char* xs = reinterpret_cast<const char*>(lds + (t & 1) * (XSW + GSW));
     const char* gs = xs + XSW * 4;
-#pragma unroll
-    for (int r = 0; r < TH; ++r) {
-#pragma unroll
-      for (int c0 = 0; c0 < TW; c0 += 16) {
-        const uint4 av = *reinterpret_cast<const uint4*>(gs + a_lane + (r * TW + c0) * 2);
-        const vec8 a = *reinterpret_cast<const vec8*>(&av);
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          const char* bp = xs + b_lane + tap_off[j] + (r * XQ + c0) * (XROWW * 4);
-          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + 4 * XROWW * 4));
-          union { struct { s16x4 l, h; } s; vec8 v; } u;
-          u.s.l = lo; u.s.h = hi;
-          acc[j] = E::mfma(a, u.v, acc[j]);
-        }
-      }
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    // explicit software pipeline over the NK 16-pixel k-steps: the fragments of step ks+1 are read (one A
+    // ds_read_b128 + 2 transposing reads per tap) BEFORE the MFMAs of step ks issue, into a second register set
+    constexpr int NK = TH * (TW / 16);
+    uint4 a_cur, a_nxt;
+    s16x4 bl_cur[TPW], bh_cur[TPW], bl_nxt[TPW], bh_nxt[TPW];
+#define WG_READ(ks_, A_, BL_, BH_)                                                                   \
+    {                                                                                                \
+      const int r_ = (ks_) / (TW / 16), c0_ = ((ks_) % (TW / 16)) * 16;                              \
+      A_ = *reinterpret_cast<const uint4*>(gs + a_lane + (r_ * TW + c0_) * 2);                       \
+      _Pragma("unroll") for (int j = 0; j < TPW; ++j) {                                              \
+        const char* bp_ = xs + b_lane + tap_off[j] + (r_ * XQ + c0_) * (XROWW * 4);                  \
+        BL_[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp_));                         \
+        BH_[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp_ + 4 * XROWW * 4));         \
+      }                                                                                              \
     }
+#define WG_MFMA(A_, BL_, BH_)                                                                        \
+    {                                                                                                \
+      const vec8 av_ = *reinterpret_cast<const vec8*>(&A_);                                          \
+      _Pragma("unroll") for (int j = 0; j < TPW; ++j) {                                              \
+        union { struct { s16x4 l, h; } s; vec8 v; } u_;                                              \
+        u_.s.l = BL_[j]; u_.s.h = BH_[j];                                                            \
+        acc[j] = E::mfma(av_, u_.v, acc[j]);                                                         \
+      }                                                                                              \
+    }
+    // NOTE: at the 256-VGPR cap hipcc re-serialises this into {2 reads, lgkmcnt(0), 1 MFMA} per tap with one
+    // fragment set; pinning the order with sched_group_barrier made it spill (20.9 vs 14.8 ms) -- the fix is fewer
+    // live staging registers (next round), not scheduling directives.
+    WG_READ(0, a_cur, bl_cur, bh_cur);
+#pragma unroll
+    for (int ks = 0; ks < NK; ks += 2) {
+      if (ks + 1 < NK) WG_READ(ks + 1, a_nxt, bl_nxt, bh_nxt);
+      WG_MFMA(a_cur, bl_cur, bh_cur);
+      if (ks + 2 < NK) WG_READ(ks + 2, a_cur, bl_cur, bh_cur);
+      if (ks + 1 < NK) WG_MFMA(a_nxt, bl_nxt, bh_nxt);
+    }
+#undef WG_READ
+#undef WG_MFMA
     if (has_next) store_tile((t + 1) & 1);
     __syncthreads();
   }

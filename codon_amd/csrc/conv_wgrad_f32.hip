@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradParam
         const int gy_ = ty0 + r - PAD, gx_ = tx0 + q - PAD;
         if (e < NCI * XR * XQ) {
           const bool ok = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
-          xs[c * XPL + rem] = ok ? xg[c * HW + (long)gy_ * W + gx_] : 0.f;
+          const float v = xg[ok ? c * HW + (long)gy_ * W + gx_ : 0];   // unconditional load, then select
+          xs[c * XPL + rem] = ok ? v : 0.f;
         }
       }
 #pragma unroll 8
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradParam
         const int r = rem / TW, q = rem - r * TW;
         const int gy_ = ty0 + r, gx_ = tx0 + q;
         const bool ok = gy_ < H && gx_ < W;
-        gs[c * GPL + rem] = ok ? gg[c * HW + (long)gy_ * W + gx_] : 0.f;
+        const float v = gg[ok ? c * HW + (long)gy_ * W + gx_ : 0];
+        gs[c * GPL + rem] = ok ? v : 0.f;
       }
       __syncthreads();
       // K loop over the tile's 128 pixels, two horizontally adjacent pixels per MFMA

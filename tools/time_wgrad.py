@@ -1,12 +1,16 @@
-import sys, torch, time
-sys.path.insert(0, "/root/repo")
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from codon_amd import ops
 from codon_amd.ops import Slice
 dev = torch.device("cuda:0")
-B, H, W = 32, 480, 640
-for (k, ci, co) in [(5, 128, 128), (5, 64, 64), (3, 64, 64), (1, 128, 64)]:
-    x = torch.randn((B, ci, H, W), device=dev)
-    g = torch.randn((B, co, H, W), device=dev)
+dt = {"f32": torch.float32, "bf16": torch.bfloat16}[sys.argv[1] if len(sys.argv) > 1 else "f32"]
+B, H, W = int(os.environ.get("B", 32)), 480, 640
+cases = [(5, 128, 128), (5, 64, 64), (3, 64, 64), (1, 128, 64)]
+if len(sys.argv) > 2:
+    cases = [cases[int(sys.argv[2])]]
+for (k, ci, co) in cases:
+    x = torch.randn((B, ci, H, W), device=dev).to(dt)
+    g = torch.randn((B, co, H, W), device=dev).to(dt)
     dw = torch.empty((co, ci, k, k), device=dev)
     ops.conv2d_wgrad(Slice(x), Slice(g), dw, k)
     torch.cuda.synchronize()
@@ -17,5 +21,5 @@ for (k, ci, co) in [(5, 128, 128), (5, 64, 64), (3, 64, 64), (1, 128, 64)]:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
     fl = 2.0 * k * k * ci * co * B * H * W
-    print(f"wgrad k{k} {ci}->{co}: {ms:.2f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+    print(f"wgrad {dt} k{k} {ci}->{co}: {ms:.2f} ms  {fl/ms/1e9:.1f} TFLOP/s")
     del x, g
