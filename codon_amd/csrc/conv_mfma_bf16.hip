@@ -20,6 +20,8 @@
 
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "codon_common.h"
 
 namespace codon {
@@ -120,25 +122,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
     xdst[k] = (((cp >> 2) * XR + r) * XQ + q) * 4 + (cp & 3);
   }
 
-  unsigned xr[XE];
+  // The two channels of a word stay in two registers until STORE_X writes them as two ds_write_b16: packing
+  // `lo | hi << 16` (or a 2-vector) at load time made hipcc wait for every prefetch load right after issuing it.
+  u16 xlo[XE], xhi[XE];
   uint4 wr[WE];
 
 #define LOAD_X(chunk_)                                                                  \
   {                                                                                     \
     const u16* src_ = xg + (long)(chunk_) * CK * HW;                                    \
     _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                    \
-      const bool m_ = (xmask >> k) & 1u;                                                \
-      /* unconditional loads (xoff = 0, in bounds, when masked): a select, not a branch + wait per load */ \
-      const unsigned lo_ = src_[xoff[k]];                                               \
-      const unsigned hi_ = src_[xoff[k] + HW];                                          \
-      xr[k] = m_ ? (lo_ | (hi_ << 16)) : 0u;                                            \
+      /* unconditional loads (xoff = 0, in bounds, when masked); the mask is applied at STORE_X */ \
+      xlo[k] = src_[xoff[k]];                                                           \
+      xhi[k] = src_[xoff[k] + HW];                                                      \
     }                                                                                   \
   }
 #define STORE_X(buf_)                                                                   \
   {                                                                                     \
-    unsigned* dst_ = reinterpret_cast<unsigned*>(xs0 + (buf_) * XS);                    \
+    u16* dst_ = reinterpret_cast<u16*>(xs0 + (buf_) * XS);                              \
     _Pragma("unroll") for (int k = 0; k < XE; ++k)                                      \
-        if (XW % 256 == 0 || tid + k * 256 < XW) dst_[xdst[k]] = xr[k];                 \
+        if (XW % 256 == 0 || tid + k * 256 < XW) {                                      \
+          const bool m_ = (xmask >> k) & 1u;                                            \
+          dst_[2 * xdst[k]] = m_ ? xlo[k] : (u16)0;                                     \
+          dst_[2 * xdst[k] + 1] = m_ ? xhi[k] : (u16)0;                                 \
+        }                                                                               \
   }
 #define LOAD_W(stage_)                                                                  \
   {                                                                                     \
@@ -208,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
 #undef LOAD_W
 #undef STORE_W
 
+  // epilogue.  The flag tests are hoisted into four wave-uniform variants so that inside a variant every
+  // residual / accumulate load is unconditional and the 16 loads of a tile are issued back to back (a per-element
+  // `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
   const int gx = tx0 + l31;
   if (gx < W) {
     u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
@@ -216,26 +225,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
     const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
     const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
     const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+    auto epi = [&](auto has_r, auto has_acc) {
 #pragma unroll
-    for (int i = 0; i < PSEG; ++i) {
-      const int gy = ty0 + wave * PSEG + i;
-      if (gy < H) {
-        const long pix = (long)gy * W + gx;
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+          const long pix = (long)gy * W + gx;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
+          for (int t = 0; t < CT; ++t) {
+            float rv[16], av[16];
+            if constexpr (decltype(has_r)::value) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[i][t][r];
-            if (relu) v = fmaxf(v, 0.f);
-            if (addr) v += E::to_f32(rg[co * HW + pix]);
-            if (mask) v = E::to_f32(rg[co * HW + pix]) > 0.f ? v : 0.f;
-            if (accum) v += E::to_f32(yg[co * HW + pix]);
-            yg[co * HW + pix] = E::from_f32(v);
+              for (int r = 0; r < 16; ++r)
+                rv[r] = E::to_f32(rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
+            }
+            if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                av[r] = E::to_f32(yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v = acc[i][t][r];
+              if (relu) v = fmaxf(v, 0.f);
+              if constexpr (decltype(has_r)::value) {
+                if (addr) v += rv[r];
+                if (mask) v = rv[r] > 0.f ? v : 0.f;
+              }
+              if constexpr (decltype(has_acc)::value) v += av[r];
+              yg[co * HW + pix] = E::from_f32(v);
+            }
           }
         }
       }
-    }
+    };
+    const bool has_r = addr || mask;
+    if (has_r && accum) epi(std::true_type{}, std::true_type{});
+    else if (has_r) epi(std::true_type{}, std::false_type{});
+    else if (accum) epi(std::false_type{}, std::true_type{});
+    else epi(std::false_type{}, std::false_type{});
   }
 }
 

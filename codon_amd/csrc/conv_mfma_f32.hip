@@ -24,6 +24,8 @@
 // staging traffic (<= 1 ds_read_b32 per MFMA) sit far below their limits; the kernel is bound
 // by the fp32 matrix rate (157 TFLOP/s chip peak).
 
+#include <type_traits>
+
 #include "codon_common.h"
 
 namespace codon {
@@ -108,15 +110,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   {                                                                                \
     const float* src_ = xg + (long)(chunk_) * CK * HW;                             \
     _Pragma("unroll") for (int k = 0; k < XE; ++k)                                 \
-        { const float v_ = src_[xoff[k]];  /* unconditional: xoff = 0 (in bounds) when masked */ \
-          xr[k] = ((xmask >> k) & 1u) ? v_ : 0.f; }                                \
+        xr[k] = src_[xoff[k]];  /* unconditional (xoff = 0, in bounds, when masked); mask applied at STORE_X */ \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \
     float* dst_ = xs0 + (buf_) * XS;                                               \
     _Pragma("unroll") for (int k = 0; k < XE; ++k) {                               \
       const int e_ = tid + k * 256;                                                \
-      if (XS % 256 == 0 || e_ < XS) dst_[e_] = xr[k];                              \
+      if (XS % 256 == 0 || e_ < XS) dst_[e_] = ((xmask >> k) & 1u) ? xr[k] : 0.f;  \
     }                                                                              \
   }
 #define LOAD_W(stage_)                                                             \
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 #undef LOAD_W
 #undef STORE_W
 
-  // epilogue: ReLU / residual / accumulate, coalesced NCHW stores
+  // epilogue: ReLU / residual / accumulate, coalesced NCHW stores.  Flag tests hoisted into four wave-uniform
+  // variants: inside a variant the residual / accumulate loads of a tile are unconditional and issued back to
+  // back (a per-element `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
   const int gx = tx0 + l31;
   if (gx < W) {
     float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
@@ -195,26 +198,44 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
     const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
     const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
     const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+    auto epi = [&](auto has_r, auto has_acc) {
 #pragma unroll
-    for (int i = 0; i < PSEG; ++i) {
-      const int gy = ty0 + wave * PSEG + i;
-      if (gy < H) {
-        const long pix = (long)gy * W + gx;
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+          const long pix = (long)gy * W + gx;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
+          for (int t = 0; t < CT; ++t) {
+            float rv[16], av[16];
+            if constexpr (decltype(has_r)::value) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[i][t][r];
-            if (relu) v = fmaxf(v, 0.f);
-            if (addr) v += rg[co * HW + pix];
-            if (mask) v = rg[co * HW + pix] > 0.f ? v : 0.f;
-            if (accum) v += yg[co * HW + pix];
-            yg[co * HW + pix] = v;
+              for (int r = 0; r < 16; ++r) rv[r] = rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+            }
+            if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) av[r] = yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v = acc[i][t][r];
+              if (relu) v = fmaxf(v, 0.f);
+              if constexpr (decltype(has_r)::value) {
+                if (addr) v += rv[r];
+                if (mask) v = rv[r] > 0.f ? v : 0.f;
+              }
+              if constexpr (decltype(has_acc)::value) v += av[r];
+              yg[co * HW + pix] = v;
+            }
           }
         }
       }
-    }
+    };
+    const bool has_r = addr || mask;
+    if (has_r && accum) epi(std::true_type{}, std::true_type{});
+    else if (has_r) epi(std::true_type{}, std::false_type{});
+    else if (accum) epi(std::false_type{}, std::true_type{});
+    else epi(std::false_type{}, std::false_type{});
   }
 }
 

@@ -43,14 +43,16 @@ struct Wgrad16Params {
   int H, W, cin, cout;
   long x_img, g_img, x_base, g_base;
   int tiles_x, band_tiles_y, nbands, nsplit;
+  int pair;  // W even and 4-byte aligned planes: 4-byte pixel-pair staging loads
 };
 
-template <class E, int KS>
+template <class E, int KS, bool PAIR>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Params p) {
   typedef typename E::vec8 vec8;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = 4;
-  constexpr int XR = TH + KS - 1, XQ = TW + KS - 1, NP = XR * XQ;
+  constexpr int PADX = (KS == 1) ? 0 : 2;   // even column origin of the halo tile, so pixel pairs stay 4-byte aligned
+  constexpr int XR = TH + KS - 1, XQ = TW + 2 * PADX, NP = XR * XQ;
   constexpr int XROWW = 18;              // 32-bit words per pixel row of xs: 16 data + 2 pad (72 B)
   constexpr int XSW = NP * XROWW;        // words per x buffer
   constexpr int GPLW = 68;               // words per cout row of gs: 128 pixels + 8 pad (272 B)
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
   for (int j = 0; j < TPW; ++j) {
     int tap = wg + 4 * j;
     if (tap >= TAPS) tap = TAPS - 1;
-    tap_off[j] = ((tap / KS) * XQ + (tap % KS)) * (XROWW * 4);
+    tap_off[j] = ((tap / KS) * XQ + (tap % KS) + (PADX - PAD)) * (XROWW * 4);
   }
 
   f32x16 acc[TPW];
@@ -100,59 +102,134 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  unsigned xr[XE], gr[GE];
+  // Staging registers.  PAIR path (W even, 4-byte aligned planes): every global access is a 4-byte pixel pair.
+  //   x : unit u = (channel pair cp, pixel pair) -> two loads d0 (ch 2cp), d1 (ch 2cp+1), each = pixels (p, p+1);
+  //       written as four ds_write_b16 at STORE time (no VALU between load and store, so the prefetch is not
+  //       consumed -- and waited for -- before the MFMAs)
+  //   gy: word = pixels (p, p+1) of one channel = the LDS word itself
+  // Fallback (odd W): 2-byte loads.
+  constexpr int XUNITS = 16 * (NP / 2);
+  constexpr int XU = (XUNITS + 511) / 512;
+  unsigned xd0[PAIR ? XU : 1], xd1[PAIR ? XU : 1], gr[PAIR ? GE : 1];
+  u16 xlo[PAIR ? 1 : XE], xhi[PAIR ? 1 : XE], glo[PAIR ? 1 : GE], ghi[PAIR ? 1 : GE];
 
   auto load_tile = [&](int t) {
     const int ty = ty_begin + t / p.tiles_x, tx = t % p.tiles_x;
     const int tx0 = tx * TW, ty0 = ty * TH;
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int k = 0; k < XE; ++k) {
-      const int e = tid + k * 512;
-      const int cp = e / NP;
-      const int pi = e - cp * NP;
-      const int r = pi / XQ, qq = pi - r * XQ;
-      const int gy_ = ty0 + r - PAD, gx_ = tx0 + qq - PAD;
-      const bool ok = e < XWORDS && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
-      const long o = ok ? (long)(2 * cp) * HW + (long)gy_ * W + gx_ : 0;   // clamped: unconditional loads
-      const unsigned lo = xg[o], hi = xg[o + HW];
-      xr[k] = ok ? (lo | (hi << 16)) : 0u;
-    }
+      for (int k = 0; k < XU; ++k) {
+        const int u = tid + k * 512;
+        const int cp = u / (NP / 2);
+        const int pw = u - cp * (NP / 2);
+        const int r = pw / (XQ / 2), q2 = (pw - r * (XQ / 2)) * 2;
+        const int gy_ = ty0 + r - PAD, gx_ = tx0 + q2 - PADX;
+        const bool ok = u < XUNITS && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;   // W even: pair in or out
+        const long o = ok ? (long)(2 * cp) * HW + (long)gy_ * W + gx_ : 0;
+        xd0[k] = *reinterpret_cast<const unsigned*>(xg + o);
+        xd1[k] = *reinterpret_cast<const unsigned*>(xg + o + HW);
+      }
 #pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      const int e = tid + k * 512;
-      const int c = e / (TH * TW / 2);
-      const int pw = e - c * (TH * TW / 2);          // pixel pair index inside the tile
-      const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
-      const int gy_ = ty0 + r, gx_ = tx0 + q2;
-      const bool rok = gy_ < H;
-      const bool ok0 = rok && gx_ < W, ok1 = rok && gx_ + 1 < W;
-      const long o = (long)c * HW + (long)gy_ * W + gx_;
-      const unsigned lo = gg[ok0 ? o : 0], hi = gg[ok1 ? o + 1 : 0];
-      gr[k] = (ok0 ? lo : 0u) | ((ok1 ? hi : 0u) << 16);
+      for (int k = 0; k < GE; ++k) {
+        const int e = tid + k * 512;
+        const int c = e / (TH * TW / 2);
+        const int pw = e - c * (TH * TW / 2);
+        const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
+        const int gy_ = ty0 + r, gx_ = tx0 + q2;
+        const bool ok = gy_ < H && gx_ < W;
+        gr[k] = *reinterpret_cast<const unsigned*>(gg + (ok ? (long)c * HW + (long)gy_ * W + gx_ : 0));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < XE; ++k) {
+        const int e = tid + k * 512;
+        const int cp = e / NP;
+        const int pi = e - cp * NP;
+        const int r = pi / XQ, qq = pi - r * XQ;
+        const int gy_ = ty0 + r - PAD, gx_ = tx0 + qq - PADX;
+        const bool ok = e < XWORDS && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+        const long o = ok ? (long)(2 * cp) * HW + (long)gy_ * W + gx_ : 0;
+        xlo[k] = xg[o];
+        xhi[k] = xg[o + HW];
+      }
+#pragma unroll
+      for (int k = 0; k < GE; ++k) {
+        const int e = tid + k * 512;
+        const int c = e / (TH * TW / 2);
+        const int pw = e - c * (TH * TW / 2);
+        const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
+        const int gy_ = ty0 + r, gx_ = tx0 + q2;
+        const bool ok0 = gy_ < H && gx_ < W, ok1 = gy_ < H && gx_ + 1 < W;
+        const long o = (long)c * HW + (long)gy_ * W + gx_;
+        glo[k] = gg[ok0 ? o : 0];
+        ghi[k] = gg[ok1 ? o + 1 : 0];
+      }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int t) {   // t: the tile the registers hold (for the zero-padding masks)
+    const int ty = ty_begin + t / p.tiles_x, tx = t % p.tiles_x;
+    const int tx0 = tx * TW, ty0 = ty * TH;
     unsigned* xs = lds + buf * (XSW + GSW);
     unsigned* gs = xs + XSW;
+    u16* xs16 = reinterpret_cast<u16*>(xs);
+    u16* gs16 = reinterpret_cast<u16*>(gs);
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int k = 0; k < XE; ++k) {
-      const int e = tid + k * 512;
-      const int cp = e / NP;
-      const int pi = e - cp * NP;
-      if (e < XWORDS) xs[pi * XROWW + cp] = xr[k];
-    }
+      for (int k = 0; k < XU; ++k) {
+        const int u = tid + k * 512;
+        const int cp = u / (NP / 2);
+        const int pw = u - cp * (NP / 2);
+        const int r = pw / (XQ / 2), q2 = (pw - r * (XQ / 2)) * 2;
+        const int gy_ = ty0 + r - PAD, gx_ = tx0 + q2 - PADX;
+        const bool ok = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+        if (u < XUNITS) {
+          const int pi = r * XQ + q2;
+          const unsigned d0 = ok ? xd0[k] : 0u, d1 = ok ? xd1[k] : 0u;
+          xs16[(pi * XROWW + cp) * 2] = (u16)d0;
+          xs16[(pi * XROWW + cp) * 2 + 1] = (u16)d1;
+          xs16[((pi + 1) * XROWW + cp) * 2] = (u16)(d0 >> 16);
+          xs16[((pi + 1) * XROWW + cp) * 2 + 1] = (u16)(d1 >> 16);
+        }
+      }
 #pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      const int e = tid + k * 512;
-      const int c = e / (TH * TW / 2);
-      const int pw = e - c * (TH * TW / 2);
-      gs[c * GPLW + pw] = gr[k];
+      for (int k = 0; k < GE; ++k) {
+        const int e = tid + k * 512;
+        const int c = e / (TH * TW / 2);
+        const int pw = e - c * (TH * TW / 2);
+        const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
+        const bool ok = ty0 + r < H && tx0 + q2 < W;
+        gs[c * GPLW + pw] = ok ? gr[k] : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < XE; ++k) {
+        const int e = tid + k * 512;
+        const int cp = e / NP;
+        const int pi = e - cp * NP;
+        const int r = pi / XQ, qq = pi - r * XQ;
+        const int gy_ = ty0 + r - PAD, gx_ = tx0 + qq - PADX;
+        const bool ok = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+        if (e < XWORDS) {
+          xs16[(pi * XROWW + cp) * 2] = ok ? xlo[k] : (u16)0;
+          xs16[(pi * XROWW + cp) * 2 + 1] = ok ? xhi[k] : (u16)0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GE; ++k) {
+        const int e = tid + k * 512;
+        const int c = e / (TH * TW / 2);
+        const int pw = e - c * (TH * TW / 2);
+        const int r = pw / (TW / 2), q2 = (pw - r * (TW / 2)) * 2;
+        const bool ok0 = ty0 + r < H && tx0 + q2 < W, ok1 = ty0 + r < H && tx0 + q2 + 1 < W;
+        gs16[(c * GPLW + pw) * 2] = ok0 ? glo[k] : (u16)0;
+        gs16[(c * GPLW + pw) * 2 + 1] = ok1 ? ghi[k] : (u16)0;
+      }
     }
   };
 
   if (ntile > 0) {
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
   }
   __syncthreads();
 
@@ -201,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
     }
 #undef WG_READ
 #undef WG_MFMA
-    if (has_next) store_tile((t + 1) & 1);
+    if (has_next) store_tile((t + 1) & 1, t + 1);
     __syncthreads();
   }
 
@@ -266,18 +343,18 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   p.x_base = d->x_coff * HW; p.g_base = d->y_coff * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.band_tiles_y = pl.band_tiles_y; p.nbands = pl.nbands; p.nsplit = pl.nsplit;
+  p.pair = (d->width % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) % 4 == 0);
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
   const bool f16 = d->dtype == CODON_F16;
-  if (d->ksize == 5) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 5>), grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 5>), grid, dim3(512), 0, stream, p);
-  } else if (d->ksize == 3) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 3>), grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 3>), grid, dim3(512), 0, stream, p);
-  } else {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, 1>), grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, 1>), grid, dim3(512), 0, stream, p);
+#define WG_LAUNCH(KS_)                                                                                         \
+  {                                                                                                            \
+    if (f16 && p.pair) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, KS_, true>), grid, dim3(512), 0, stream, p);        \
+    else if (f16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WF16, KS_, false>), grid, dim3(512), 0, stream, p);            \
+    else if (p.pair) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, KS_, true>), grid, dim3(512), 0, stream, p);         \
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WBf16, KS_, false>), grid, dim3(512), 0, stream, p);                    \
   }
+  if (d->ksize == 5) WG_LAUNCH(5) else if (d->ksize == 3) WG_LAUNCH(3) else WG_LAUNCH(1)
+#undef WG_LAUNCH
   int st = check_launch("conv_wgrad_bf16_kernel");
   if (st != CODON_OK) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
