@@ -34,6 +34,9 @@ int conv2d_wgrad_f32(const codon_conv_desc*, const float*, const float*, float*,
 size_t conv_wgrad_bf16_workspace_bytes(const codon_conv_desc*);
 int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
+bool conv_f32x3_supported(const codon_conv_desc*);
+int conv2d_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const float*, hipStream_t);
+int pack_weight_f32x3(const float*, void*, int, int, int, hipStream_t);
 int stem_fwd(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
 size_t conv1ch_wgrad_workspace_bytes(int, int, int);
 int conv1ch_wgrad(int, int, int, const void*, int, int, const float*, float*, int, float*, size_t, int, hipStream_t);
@@ -93,6 +96,11 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
                            int32_t mode, int32_t dtype, codon_stream_t stream) {
   CODON_REQUIRE(w_oihw && w_packed, CODON_ERR_BAD_ARG, "conv_pack_weight: null pointer");
   CODON_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, CODON_ERR_UNSUPPORTED, "conv_pack_weight: ksize %d", ksize);
+  if (mode == CODON_PACK_FWD_F16X3) {
+    CODON_REQUIRE(dtype == CODON_F32 && (ksize == 3 || ksize == 5) && cin % 16 == 0 && cout % 64 == 0,
+                  CODON_ERR_UNSUPPORTED, "conv_pack_weight: f16x3 packing needs fp32, k in {3,5}, cin%%16==0, cout%%64==0");
+    return pack_weight_f32x3(w_oihw, w_packed, cout, cin, ksize, (hipStream_t)stream);
+  }
   CODON_REQUIRE(mode == CODON_PACK_FWD || mode == CODON_PACK_DGRAD, CODON_ERR_BAD_ARG, "conv_pack_weight: mode %d", mode);
   const int kin = mode == CODON_PACK_DGRAD ? cout : cin;
   CODON_REQUIRE(cout > 0 && cin > 0 && kin % conv_ck(ksize) == 0, CODON_ERR_UNSUPPORTED,
@@ -125,6 +133,11 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
   if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
     return conv2d_fwd_bf16(d, x, w_packed, y, residual, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_fwd: dtype %d", d->dtype);
+  if (d->flags & CODON_CONV_F16X3) {
+    CODON_REQUIRE(conv_f32x3_supported(d), CODON_ERR_UNSUPPORTED, "conv2d_fwd: no f16x3 kernel for k=%d cin=%d cout=%d",
+                  d->ksize, d->cin, d->cout);
+    return conv2d_fwd_f32x3(d, (const float*)x, w_packed, (float*)y, (const float*)residual, (hipStream_t)stream);
+  }
   return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
                         (hipStream_t)stream);
 }

@@ -1,0 +1,334 @@
+// OPT-IN split-precision convolution for the fp32 path ("f16x3"): fp32 activations and weights in HBM, fp32
+// accumulate, but every operand is split x = hi + lo (two fp16 values, 11 + 11 significand bits) on the way into
+// LDS and each product is evaluated as  Wh*Xh + Wh*Xl + Wl*Xh  with three v_mfma_f32_32x32x16_f16.
+//
+// Why: gfx950 has no xf32/TF32 matrix path; v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate
+// (157 TF chip peak), which bounds BASELINE configs[1] at 928 ms.  Three f16 MFMAs cost 3/16 of one fp32 MFMA
+// step's time for the same K, i.e. a 5.3x higher ceiling (~830 TF-equivalent), with a per-product relative error
+// of ~2^-22 (the dropped Wl*Xl term and the residual of the two-term split) -- 4x the fp32 rounding unit, far
+// inside the 1e-4 RMSE parity bar (measured in tests/test_gpu_f16x3.py).  NOT the default: bench.py's headline
+// line is the exact-fp32 kernel; this mode is selected with model.set_conv_precision("f16x3").
+//
+// Range: |activation| must stay below 65504 (fp16 max).  Weights are pre-scaled by 2^10 when packed (exact; moves
+// Wl out of the fp16 subnormal range) and the accumulator is scaled back by 2^-10 in the epilogue (exact).
+//
+// Structure = conv_mfma_bf16.hip (channel-blocked LDS images, (chunk of 16 channels, filter row) stages, next stage
+// prefetched to registers before the MFMAs and converted/written after them), with two images per operand.
+// Workgroup tile: 8 rows x 32 pixels x 64 couts (blockIdx also walks cout halves when COUT = 128) so that
+// xs (hi+lo, single-buffered) + ws (hi+lo, double-buffered) = 67.6 KB -> two workgroups per CU.
+
+#include <type_traits>
+
+#include "codon_common.h"
+
+namespace codon {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int F3_WSCALE_LOG2 = 10;
+
+struct ConvS3Params {
+  const float* x;
+  const uint4* w;  // packed: [cout64 block][chunk][dy][part (hi, lo)][dx][cb (2)][64 cout] x 16 B
+  float* y;
+  const float* res;
+  int H, W;
+  long x_img, y_img, r_img;
+  long x_base, y_base, r_base;
+  int tiles_x, tiles_y, nblk, ncob;
+  int flags;
+};
+
+__device__ __forceinline__ u16 f2h_bits(float f) {
+  const _Float16 h = (_Float16)f;
+  return *reinterpret_cast<const u16*>(&h);
+}
+__device__ __forceinline__ float h2f_bits(u16 v) { return (float)*reinterpret_cast<const _Float16*>(&v); }
+
+template <int KS, int CIN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Params p) {
+  constexpr int PAD = KS / 2;
+  constexpr int PSEG = 2, COUTB = 64, CT = 2;
+  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
+  constexpr int CK = 16, NCB = 2;
+  constexpr int NCHUNK = CIN / CK;
+  constexpr int XS = NCB * XR * XQ;          // 16-byte elements per x image (hi or lo)
+  constexpr int WS1 = KS * NCB * COUTB;      // 16-byte elements per weight part of a stage
+  constexpr int WS = 2 * WS1;                // hi + lo
+  constexpr int NST = NCHUNK * KS;
+  constexpr int XW = (CK / 2) * XR * XQ;     // channel-pair words per x tile
+  constexpr int XE = (XW + 255) / 256;
+  constexpr int WE = (WS + 255) / 256;
+
+  __shared__ uint4 lds[2 * XS + 2 * WS];
+  uint4* const xh = lds;            // x hi image
+  uint4* const xl = lds + XS;       // x lo image
+  uint4* const ws0 = lds + 2 * XS;  // two weight stage buffers, each [part][dx][cb][cout]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int cob = bid % p.ncob;
+  bid /= p.ncob;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int tx0 = tx * TW, ty0 = ty * TH;
+  const int H = p.H, W = p.W;
+  const long HW = (long)H * W;
+
+  const float* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
+  const uint4* __restrict__ wg = p.w + (long)cob * NST * WS;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (int)((unsigned)CIN * 4u * (unsigned)HW), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WS * 16), 0x00020000);
+
+  unsigned xoff[XE];
+  int xdst[XE];
+  unsigned xmask = 0;
+#pragma unroll
+  for (int k = 0; k < XE; ++k) {
+    const int e = tid + k * 256;
+    const int cp = e / (XR * XQ);
+    const int rem = e - cp * (XR * XQ);
+    const int r = rem / XQ, q = rem - r * XQ;
+    const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+    const bool ok = (e < XW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    xoff[k] = ok ? 4u * (unsigned)((2 * cp) * HW + (long)gy * W + gx) : 0u;   // byte offset in the image slice
+    xmask |= ok ? (1u << k) : 0u;
+    xdst[k] = (((cp >> 2) * XR + r) * XQ + q) * 4 + (cp & 3);                 // 32-bit word inside an image
+  }
+
+  float x0[XE], x1[XE];  // the two channels of a word, raw fp32, until the split at store time
+  uint4 wr[WE];
+
+#define LOAD_X(chunk_)                                                                   \
+  {                                                                                      \
+    const unsigned so_ = (unsigned)(chunk_) * (unsigned)(CK * 4) * (unsigned)HW;         \
+    const unsigned so1_ = so_ + 4u * (unsigned)HW;                                       \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                     \
+      x0[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[k], so_, 0));  \
+      x1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[k], so1_, 0)); \
+    }                                                                                    \
+  }
+#define STORE_X()                                                                        \
+  {                                                                                      \
+    unsigned* dh_ = reinterpret_cast<unsigned*>(xh);                                     \
+    unsigned* dl_ = reinterpret_cast<unsigned*>(xl);                                     \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k)                                       \
+        if (XW % 256 == 0 || tid + k * 256 < XW) {                                       \
+          const bool m_ = (xmask >> k) & 1u;                                             \
+          const float a_ = m_ ? x0[k] : 0.f, b_ = m_ ? x1[k] : 0.f;                      \
+          const u16 ah_ = f2h_bits(a_), bh_ = f2h_bits(b_);                              \
+          const u16 al_ = f2h_bits(a_ - h2f_bits(ah_)), bl_ = f2h_bits(b_ - h2f_bits(bh_)); \
+          dh_[xdst[k]] = (unsigned)ah_ | ((unsigned)bh_ << 16);                          \
+          dl_[xdst[k]] = (unsigned)al_ | ((unsigned)bl_ << 16);                          \
+        }                                                                                \
+  }
+#define LOAD_W(stage_)                                                                   \
+  {                                                                                      \
+    const unsigned wso_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                     \
+      const unsigned vo_ = (WS % 256 == 0 || tid + k * 256 < WS) ? (unsigned)(tid + k * 256) * 16u : 0u; \
+      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo_, wso_, 0);         \
+      wr[k] = *reinterpret_cast<const uint4*>(&v_);                                      \
+    }                                                                                    \
+  }
+#define STORE_W(buf_)                                                                    \
+  {                                                                                      \
+    uint4* dst_ = ws0 + (buf_) * WS;                                                     \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                       \
+        if (WS % 256 == 0 || tid + k * 256 < WS) dst_[tid + k * 256] = wr[k];            \
+  }
+
+  f32x16 acc[PSEG][CT];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  LOAD_X(0);
+  LOAD_W(0);
+  STORE_X();
+  STORE_W(0);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < NST; ++s) {
+    const int chunk = s / KS;
+    const int dy = s - chunk * KS;
+    const bool has_next = (s + 1 < NST);
+    const bool next_chunk = has_next && (dy == KS - 1);
+    if (has_next) LOAD_W(s + 1);
+    if (next_chunk) LOAD_X(chunk + 1);
+
+    const uint4* xbh = xh + (half * XR + wave * PSEG + dy) * XQ + l31;
+    const uint4* xbl = xl + (half * XR + wave * PSEG + dy) * XQ + l31;
+    const uint4* wbh = ws0 + (s & 1) * WS + half * COUTB + l31;
+    const uint4* wbl = wbh + WS1;
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      f16x8 ah[CT], al[CT], bh[PSEG], bl[PSEG];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const uint4 v = wbh[dx * NCB * COUTB + t * 32], u = wbl[dx * NCB * COUTB + t * 32];
+        ah[t] = *reinterpret_cast<const f16x8*>(&v);
+        al[t] = *reinterpret_cast<const f16x8*>(&u);
+      }
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const uint4 v = xbh[i * XQ + dx], u = xbl[i * XQ + dx];
+        bh[i] = *reinterpret_cast<const f16x8*>(&v);
+        bl[i] = *reinterpret_cast<const f16x8*>(&u);
+      }
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[i], acc[i][t], 0, 0, 0);   // small terms first
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[i], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[i], acc[i][t], 0, 0, 0);
+        }
+    }
+
+    if (has_next) STORE_W((s + 1) & 1);
+    if (next_chunk) {
+      __syncthreads();   // x images are single-buffered: every wave is done reading this chunk
+      STORE_X();
+    }
+    __syncthreads();
+  }
+#undef LOAD_X
+#undef STORE_X
+#undef LOAD_W
+#undef STORE_W
+
+  const int gx = tx0 + l31;
+  if (gx < W) {
+    float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
+    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
+    const bool relu = p.flags & CODON_CONV_RELU;
+    const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
+    const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+    constexpr float unscale = 1.f / (float)(1 << F3_WSCALE_LOG2);
+    auto epi = [&](auto has_r, auto has_acc) {
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+          const long pix = (long)gy * W + gx;
+#pragma unroll
+          for (int t = 0; t < CT; ++t) {
+            float rv[16], av[16];
+            if constexpr (decltype(has_r)::value) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+            }
+            if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) av[r] = yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v = acc[i][t][r] * unscale;
+              if (relu) v = fmaxf(v, 0.f);
+              if constexpr (decltype(has_r)::value) {
+                if (addr) v += rv[r];
+                if (mask) v = rv[r] > 0.f ? v : 0.f;
+              }
+              if constexpr (decltype(has_acc)::value) v += av[r];
+              yg[co * HW + pix] = v;
+            }
+          }
+        }
+      }
+    };
+    const bool has_r = addr || mask;
+    if (has_r && accum) epi(std::true_type{}, std::true_type{});
+    else if (has_r) epi(std::true_type{}, std::false_type{});
+    else if (accum) epi(std::false_type{}, std::true_type{});
+    else epi(std::false_type{}, std::false_type{});
+  }
+}
+
+// OIHW fp32 -> [cout64 block][chunk][dy][part][dx][cb (2)][64 cout][8 ch] fp16, scaled by 2^10, split hi/lo
+__global__ void pack_weight_f32x3_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks) {
+  const long n = (long)cout * cin * ks * ks;  // elements per part
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int j = t % 8; t /= 8;
+    const int o = t % 64; t /= 64;
+    const int cb = t % 2; t /= 2;
+    const int dx = t % ks; t /= ks;
+    const int dy = t % ks; t /= ks;
+    const int nchunk = cin / 16;
+    const int chunk = t % nchunk; t /= nchunk;
+    const int cob = (int)t;
+    const int ci = chunk * 16 + cb * 8 + j, co = cob * 64 + o;
+    const float v = w[(((long)co * cin + ci) * ks + dy) * ks + dx] * (float)(1 << F3_WSCALE_LOG2);
+    const u16 hi = f2h_bits(v);
+    const u16 lo = f2h_bits(v - h2f_bits(hi));
+    // destination: stage (cob, chunk, dy) holds [part][dx][cb][o][j]
+    const long stage = ((long)cob * nchunk + chunk) * ks + dy;
+    const long within = (((long)dx * 2 + cb) * 64 + o) * 8 + j;
+    const long part = (long)ks * 2 * 64 * 8;
+    out[stage * 2 * part + within] = hi;
+    out[stage * 2 * part + part + within] = lo;
+  }
+}
+
+template <int KS, int CIN>
+static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, float* y, const float* res,
+                     hipStream_t stream) {
+  ConvS3Params p;
+  p.x = x; p.w = (const uint4*)w; p.y = y; p.res = res;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = d->r_ctotal * HW;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + 7) / 8;
+  p.ncob = d->cout / 64;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch * p.ncob;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+  hipLaunchKernelGGL((conv_mfma_f32x3_kernel<KS, CIN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_mfma_f32x3_kernel");
+}
+
+bool conv_f32x3_supported(const codon_conv_desc* d) {
+  return (d->ksize == 3 || d->ksize == 5) && (d->cin == 64 || d->cin == 128) && (d->cout == 64 || d->cout == 128);
+}
+
+int conv2d_fwd_f32x3(const codon_conv_desc* d, const float* x, const void* w, float* y, const float* res,
+                     hipStream_t stream) {
+  const int key = d->ksize * 1000 + d->cin;
+  switch (key) {
+    case 5128: return launch_s3<5, 128>(d, x, w, y, res, stream);
+    case 5064: return launch_s3<5, 64>(d, x, w, y, res, stream);
+    case 3064: return launch_s3<3, 64>(d, x, w, y, res, stream);
+    case 3128: return launch_s3<3, 128>(d, x, w, y, res, stream);
+    default:
+      set_error("conv2d_fwd: no f16x3 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      return CODON_ERR_UNSUPPORTED;
+  }
+}
+
+int pack_weight_f32x3(const float* w, void* out, int cout, int cin, int ks, hipStream_t stream) {
+  const long n = (long)cout * cin * ks * ks;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_f32x3_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks);
+  return check_launch("pack_weight_f32x3_kernel");
+}
+
+}  // namespace codon

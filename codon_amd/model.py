@@ -115,6 +115,17 @@ class _CODONBase(nn.Module):
             self.attention_s5 = CAC_spatial()
         self._pack_cache: Dict[str, tuple] = {}
         self.compute_dtype: Optional[torch.dtype] = None
+        self.conv_precision: str = "exact"
+
+    def set_conv_precision(self, mode: str):
+        """fp32 path only.  "exact" (default): v_mfma_f32_32x32x2_f32, bitwise fp32 fmaf chains.
+        "f16x3": OPT-IN split-precision evaluation of the 3x3 / 5x5 convs (operands split into fp16 hi+lo,
+        three f16 MFMAs per product, fp32 accumulate; ~2^-22 relative per product, |activations| < 65504) --
+        the way off the 157 TF fp32-MFMA ceiling on gfx950, which has no TF32.  Inference only."""
+        if mode not in ("exact", "f16x3"):
+            raise ValueError(mode)
+        self.conv_precision = mode
+        return self
 
     def set_compute_dtype(self, dtype: Optional[torch.dtype]):
         """Activation / MFMA operand dtype: None = follow the parameters' dtype; torch.bfloat16 with fp32
@@ -135,6 +146,8 @@ class _CODONBase(nn.Module):
     def _packed(self, name: str, mode: int = L.PACK_FWD) -> torch.Tensor:
         w = getattr(self, name).weight
         adt = self._act_dtype()
+        if mode == L.PACK_FWD and self._split(w.shape[-1]):
+            mode = L.PACK_FWD_F16X3
         key = (name, mode, adt)
         tag = (w.data_ptr(), w._version, w.device, w.dtype)
         hit = self._pack_cache.get(key)
@@ -143,6 +156,10 @@ class _CODONBase(nn.Module):
         packed = ops.packed_weight(w.detach(), mode, adt)
         self._pack_cache[key] = (tag, packed)
         return packed
+
+    def _split(self, ksize: int) -> bool:
+        return (getattr(self, "conv_precision", "exact") == "f16x3" and ksize in (3, 5)
+                and self._act_dtype() == torch.float32)
 
     def __getstate__(self):  # pickle / deepcopy: drop the device-side cache
         d = self.__dict__.copy()
@@ -166,6 +183,9 @@ class _CODONBase(nn.Module):
             raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16, fp16)")
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
+            if self.conv_precision != "exact":
+                raise NotImplementedError("codon_amd.CODONNet: conv_precision='f16x3' is inference-only "
+                                          "(the backward kernels are exact fp32); call under torch.no_grad()")
             if adt == torch.float16:
                 raise NotImplementedError("codon_amd.CODONNet: fp16 is inference-only (as in the reference, "
                                           "test.py:52); train in fp32 or bf16, or call under torch.no_grad()")
@@ -183,16 +203,20 @@ class _CODONBase(nn.Module):
         new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
         P = self._packed
         keep = save is not None
+
+        def conv(xs, name, ys, k, **kw):   # one MFMA conv; 3x3 / 5x5 take the split-precision kernel when opted in
+            ops.conv2d(xs, P(name), ys, k, f16x3=self._split(k), **kw)
+
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
         in2 = new(128)
         t64 = new(64)
         ops.stem(x, f32(self.input.weight), Slice(t64))
-        ops.conv2d(Slice(t64), P("conv_input"), Slice(in2, 0, 64), 3, relu=True)
+        conv(Slice(t64), "conv_input", Slice(in2, 0, 64), 3, relu=True)
         t64c = new(64) if keep else t64
         ops.stem(y, f32(self.input_c.weight), Slice(t64c))
-        ops.conv2d(Slice(t64c), P("conv_input_c"), Slice(in2, 64, 64), 3, relu=True)
+        conv(Slice(t64c), "conv_input_c", Slice(in2, 64, 64), 3, relu=True)
         inputs, inputs_c = Slice(in2, 0, 64), Slice(in2, 64, 64)
         if keep:
             save["stem"], save["stem_c"], save["in2"] = t64, t64c, in2
@@ -213,15 +237,15 @@ class _CODONBase(nn.Module):
             out, out_c = Slice(cur, 0, 64), Slice(cur, 64, 64)
             pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
-            ops.conv2d(out, P("conv1"), Slice(stage, 0, 64), 3, relu=True)
-            ops.conv2d(out, P("conv2"), Slice(stage, 64, 64), 5, relu=True)
-            ops.conv2d(Slice(stage), P("conv3"), Slice(r2), 5, relu=True)          # :81
-            ops.conv2d(Slice(r2), P("confuse"), pre, 1)                            # :84
+            conv(out, "conv1", Slice(stage, 0, 64), 3, relu=True)
+            conv(out, "conv2", Slice(stage, 64, 64), 5, relu=True)
+            conv(Slice(stage), "conv3", Slice(r2), 5, relu=True)          # :81
+            conv(Slice(r2), "confuse", pre, 1)                            # :84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
-            ops.conv2d(out_c, P("conv4"), Slice(stage_c, 0, 64), 5, relu=True)
-            ops.conv2d(out_c, P("conv5"), Slice(stage_c, 64, 64), 3, relu=True)
-            ops.conv2d(Slice(stage_c), P("conv6"), Slice(r2_c), 5, relu=True)      # :82
-            ops.conv2d(Slice(r2_c), P("confuse_c"), pre_c, 1)                      # :83
+            conv(out_c, "conv4", Slice(stage_c, 0, 64), 5, relu=True)
+            conv(out_c, "conv5", Slice(stage_c, 64, 64), 3, relu=True)
+            conv(Slice(stage_c), "conv6", Slice(r2_c), 5, relu=True)      # :82
+            conv(Slice(r2_c), "confuse_c", pre_c, 1)                      # :83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
             ops.cac_stats(pre_c, pre, pooled, partials)
@@ -238,7 +262,7 @@ class _CODONBase(nn.Module):
 
         # fusion trunk                                                               :119-128
         fuse = new(64)
-        ops.conv2d(Slice(cur), P("conv7"), Slice(fuse), 3, relu=True)
+        conv(Slice(cur), "conv7", Slice(fuse), 3, relu=True)
         if keep:
             save["oc"], save["fuse"] = cur, fuse
         f = fuse
@@ -247,16 +271,16 @@ class _CODONBase(nn.Module):
         for i in range(3):
             if keep:
                 stage, r2, fA = new(128), new(128), new(64)
-            ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True)    # :123
-            ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True)   # :124
-            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True)         # :126
+            conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
+            conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
+            conv(Slice(stage), "conv10", Slice(r2), 5, relu=True)         # :126
             ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))  # :127-128
             if keep:
                 save[f"trunk{i}"] = dict(x=f, stage=stage, r2=r2)
             f = fA
         # tail                                                                       :129-132
         t = new(64) if keep else t64
-        ops.conv2d(Slice(f), P("conv11"), Slice(t), 3, relu=True)
+        conv(Slice(f), "conv11", Slice(t), 3, relu=True)
         outp = torch.empty_like(x)
         ops.head(Slice(t), f32(self.output.weight), x, outp)
         if keep:

@@ -88,7 +88,8 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
 
 
 def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = False,
-           residual: Optional[Slice] = None, accumulate: bool = False, relu_mask: Optional[Slice] = None):
+           residual: Optional[Slice] = None, accumulate: bool = False, relu_mask: Optional[Slice] = None,
+           f16x3: bool = False):
     """y = conv(x) [relu] [+ residual] ; relu_mask: y = (relu_mask > 0) ? conv(x) : 0 (backward through a
     ReLU given its output); accumulate: y += result."""
     if relu_mask is not None:
@@ -98,7 +99,7 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
     dev = _dev(x.buf, w_packed, y.buf, residual.buf if residual else None)
     B, _, H, W = x.buf.shape
     assert y.buf.shape[0] == B and y.buf.shape[2:] == x.buf.shape[2:]
-    flags = (L.CONV_RELU if relu else 0) | (L.CONV_ACCUM_OUT if accumulate else 0)
+    flags = (L.CONV_RELU if relu else 0) | (L.CONV_ACCUM_OUT if accumulate else 0) | (L.CONV_F16X3 if f16x3 else 0)
     if relu_mask is not None:
         flags |= L.CONV_MASK_RELU
     elif residual is not None:

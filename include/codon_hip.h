@@ -42,11 +42,14 @@ enum {
   CODON_CONV_RELU = 1,         /* y = max(conv, 0)          (self.relu(self.convN(..)))      */
   CODON_CONV_ADD_RESIDUAL = 2, /* y = conv + residual       (torch.add(out_fuse, fuse) :128) */
   CODON_CONV_ACCUM_OUT = 4,    /* y += conv                 (backward: grads that fan in)    */
-  CODON_CONV_MASK_RELU = 8     /* y = residual > 0 ? conv : 0   (backward through a ReLU whose OUTPUT is
+  CODON_CONV_MASK_RELU = 8,    /* y = residual > 0 ? conv : 0   (backward through a ReLU whose OUTPUT is
                                   passed in the residual slot; applied before ACCUM_OUT's add)      */
+  CODON_CONV_F16X3 = 16        /* OPT-IN, fp32 tensors, k in {3,5}: split-precision evaluation -- operands split
+                                  into fp16 hi+lo, three f16 MFMAs per product, fp32 accumulate (~2^-22 per
+                                  product; |activations| < 65504).  w_packed must come from CODON_PACK_FWD_F16X3. */
 };
 
-enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1 };
+enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2 };
 
 /* One stride-1, "same"-padded, bias-free 2-D convolution (every nn.Conv2d of
  * CODON_X4/CODON_x4.py:24-47 has stride 1, padding k//2, bias=False). */
