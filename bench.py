@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8, 16])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default). gloo only to rehearse the multi-rank path on one GPU")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: BASELINE configs[1] (default); bf16: bf16 activations/weights, fp32 accumulate + master weights")
     ap.add_argument("--conv-precision", choices=["exact", "f16x3"], default="exact",
@@ -173,13 +175,18 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if a.backend == "gloo" else local   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group("gloo")
 
     from codon_amd import CODONNet, CODONNet16, ops
     B, H, W = a.batch, a.height, a.width
