@@ -341,6 +341,24 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
     ok[i] = px[i] < HW;
   }
 
+  // ALL activation loads of the wave are issued before the first MFMA (NKS*8 registers): one memory round trip
+  // per wave instead of one per k-step (hipcc otherwise emits {8 loads, wait, MFMAs} per k-step)
+  unsigned dd[NKS][PAIRED ? 8 : 16];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if constexpr (PAIRED) {
+      const u16* src = xg + (long)(ks * 16 + half * 8) * HW + (pok ? pp : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dd[ks][j] = *reinterpret_cast<const unsigned*>(src + j * HW);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u16* src = xg + (long)(ks * 16 + half * 8) * HW + (ok[i] ? px[i] : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[ks][i * 8 + j] = src[j * HW];
+      }
+    }
+  }
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     vec8 a[CT], bv[2];
@@ -350,15 +368,12 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
       a[t] = *reinterpret_cast<const vec8*>(&v);
     }
     if constexpr (PAIRED) {
-      const u16* src = xg + (long)(ks * 16 + half * 8) * HW + pp;
-      unsigned d[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) d[j] = pok ? *reinterpret_cast<const unsigned*>(src + j * HW) : 0u;
       unsigned e[4], o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        e[j] = (d[2 * j] & 0xffffu) | (d[2 * j + 1] << 16);          // even pixel: channels 2j, 2j+1
-        o[j] = (d[2 * j] >> 16) | (d[2 * j + 1] & 0xffff0000u);      // odd pixel
+        const unsigned d0 = pok ? dd[ks][2 * j] : 0u, d1 = pok ? dd[ks][2 * j + 1] : 0u;
+        e[j] = (d0 & 0xffffu) | (d1 << 16);          // even pixel: channels 2j, 2j+1
+        o[j] = (d0 >> 16) | (d1 & 0xffff0000u);      // odd pixel
       }
       const uint4 ve = make_uint4(e[0], e[1], e[2], e[3]), vo = make_uint4(o[0], o[1], o[2], o[3]);
       bv[0] = *reinterpret_cast<const vec8*>(&ve);
@@ -366,12 +381,10 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const u16* src = xg + (long)(ks * 16 + half * 8) * HW + px[i];
         unsigned w4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const unsigned lo = ok[i] ? src[(2 * j) * HW] : 0u;
-          const unsigned hi = ok[i] ? src[(2 * j + 1) * HW] : 0u;
+          const unsigned lo = ok[i] ? dd[ks][i * 8 + 2 * j] : 0u, hi = ok[i] ? dd[ks][i * 8 + 2 * j + 1] : 0u;
           w4[j] = lo | (hi << 16);
         }
         const uint4 v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
@@ -385,48 +398,87 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
         acc[i][t] = E::mfma(a[t], bv[i], acc[i][t]);
   }
 
-  if constexpr (PAIRED) {
-    if (pok) {
+  // epilogue: flag tests hoisted into wave-uniform variants; inside a variant the 16 residual / accumulate loads
+  // of a cout tile are unconditional and issued back to back (see conv_mfma_bf16_kernel)
+  auto epi = [&](auto has_r, auto has_acc) {
+    if constexpr (PAIRED) {
+      if (pok) {
+        // residual / accumulate words are loaded G cout tiles at a time before the stores of that group:
+        // G = CT when the registers allow it (CT = 2: 32 + 32 words), else one tile (16 + 16) at a time
+        constexpr int G = (CT <= 2) ? CT : 1;
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
+        for (int t0 = 0; t0 < CT; t0 += G) {
+          unsigned rm[G][16], am[G][16];
+          if constexpr (decltype(has_r)::value) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v0 = acc[0][t][r], v1 = acc[1][t][r];
-        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (rg) {
-          const unsigned m = *reinterpret_cast<const unsigned*>(rg + co * HW + pp);
-          const float m0 = E::lo(m), m1 = E::hi(m);
-          if (addr) { v0 += m0; v1 += m1; }
-          if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                rm[g][r] = *reinterpret_cast<const unsigned*>(rg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pp);
+          }
+          if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                am[g][r] = *reinterpret_cast<const unsigned*>(yg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pp);
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int t = t0 + g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v0 = acc[0][t][r], v1 = acc[1][t][r];
+              if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+              if constexpr (decltype(has_r)::value) {
+                const float m0 = E::lo(rm[g][r]), m1 = E::hi(rm[g][r]);
+                if (addr) { v0 += m0; v1 += m1; }
+                if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
+              }
+              if constexpr (decltype(has_acc)::value) { v0 += E::lo(am[g][r]); v1 += E::hi(am[g][r]); }
+              *reinterpret_cast<unsigned*>(yg + co * HW + pp) =
+                  (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+            }
+          }
         }
-        if (accum) {
-          const unsigned m = *reinterpret_cast<const unsigned*>(yg + co * HW + pp);
-          v0 += E::lo(m); v1 += E::hi(m);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!ok[i]) continue;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          float rv[16], av[16];
+          if constexpr (decltype(has_r)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = E::to_f32(rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + px[i]]);
+          }
+          if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = E::to_f32(yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + px[i]]);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][t][r];
+            if (relu) v = fmaxf(v, 0.f);
+            if constexpr (decltype(has_r)::value) {
+              if (addr) v += rv[r];
+              if (mask) v = rv[r] > 0.f ? v : 0.f;
+            }
+            if constexpr (decltype(has_acc)::value) v += av[r];
+            yg[co * HW + px[i]] = E::from_f32(v);
+          }
         }
-        *reinterpret_cast<unsigned*>(yg + co * HW + pp) = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
       }
     }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (!ok[i]) continue;
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[i][t][r];
-          if (relu) v = fmaxf(v, 0.f);
-          if (addr) v += E::to_f32(rg[co * HW + px[i]]);
-          if (mask) v = E::to_f32(rg[co * HW + px[i]]) > 0.f ? v : 0.f;
-          if (accum) v += E::to_f32(yg[co * HW + px[i]]);
-          yg[co * HW + px[i]] = E::from_f32(v);
-        }
-      }
-    }
-  }
+  };
+  const bool has_r = addr || mask;
+  if (has_r && accum) epi(std::true_type{}, std::true_type{});
+  else if (has_r) epi(std::true_type{}, std::false_type{});
+  else if (accum) epi(std::false_type{}, std::true_type{});
+  else epi(std::false_type{}, std::false_type{});
   }  // it
 }
 
