@@ -245,53 +245,62 @@ int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const
 //   R[c][t] = sum_{b,q} A[b,c,q] * s[b, q + (t/3 - 1, t%3 - 1)]        c < 64, t < 9
 //   stem: A = dL/d(conv output, ReLU-masked), s = x      -> input.weight.grad[c][0][t]  = R[c][t]
 //   head: A = t11 (the head's input),         s = dL/dy  -> output.weight.grad[0][c][t] = R[c][8-t]
-// GEMM M = 64 channels, N = 9 taps (padded to 32), K = pixels, on v_mfma_f32_32x32x2_f32 with operands
-// loaded straight from global memory (each 128-byte line of a channel plane is reused by the next
-// 16 k-steps out of L1).  0.01 % of the FLOPs: simplicity over speed.  Per-wave partials -> fixed-order sum.
-constexpr int W1_ROWS = 8;  // image rows per workgroup (2 per wave)
+// HBM-bound (one read of the 64-channel tensor A): lanes walk x so every A load is a coalesced row segment;
+// the 3x3 window of the 1-channel map s is loaded once per (row, 64-pixel chunk) and reused by all channels.
+// Workgroup = (image, band of W1_ROWS rows); wave w owns channels 16w .. 16w+15 and keeps their 16 x 9 partial
+// sums in registers over the whole band; one wave reduction per sum at the end, per-block partials, fixed-order
+// final sum (deterministic).
+constexpr int W1_ROWS = 8;
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const T* __restrict__ a, long a_img, long a_base,
                                                             const float* __restrict__ s, float* __restrict__ part,
                                                             int H, int W, int nrowblk) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, k = lane >> 5;
   const int b = blockIdx.x / nrowblk, rb = blockIdx.x % nrowblk;
   const long HW = (long)H * W;
-  const T* ab = a + b * a_img + a_base;
+  const T* ab = a + b * a_img + a_base + (long)(wave * 16) * HW;
   const float* sb = s + (long)b * HW;
-  const int dy = l31 / 3 - 1, dx = l31 % 3 - 1;
-  f32x16 acc0, acc1;
+  float acc[16][9];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  for (int rr = wave; rr < W1_ROWS; rr += 4) {
-    const int y = rb * W1_ROWS + rr;
-    if (y >= H) break;
-    const int yy = y + dy;
-    const bool yok = l31 < 9 && yy >= 0 && yy < H;
-    const T* a0 = ab + (long)l31 * HW + (long)y * W;
-    const T* a1 = a0 + 32 * HW;
-    const float* srow = sb + (long)yy * W;
-    for (int x0 = 0; x0 < W; x0 += 2) {
-      const int x = x0 + k;
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  const int y0 = rb * W1_ROWS, y1 = min(y0 + W1_ROWS, H);
+  for (int y = y0; y < y1; ++y) {
+    for (int x0 = 0; x0 < W; x0 += 64) {
+      const int x = x0 + lane;
       const bool xin = x < W;
-      const float va0 = xin ? ldx(a0 + x) : 0.f;
-      const float va1 = xin ? ldx(a1 + x) : 0.f;
-      const int xx = x + dx;
-      const float vb = (yok && xin && xx >= 0 && xx < W) ? srow[xx] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc1, 0, 0, 0);
-    }
-  }
-  if (l31 < 9) {
-    float* o = part + ((long)blockIdx.x * 4 + wave) * 576;
+      float sv[9];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = (r & 3) + 8 * (r >> 2) + 4 * k;
-      o[c * 9 + l31] = acc0[r];
-      o[(32 + c) * 9 + l31] = acc1[r];
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool ok = xin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = sb[ok ? (long)yy * W + xx : 0];
+        sv[t] = ok ? v : 0.f;
+      }
+      const long off = xin ? (long)y * W + x : 0;
+      float av[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) av[c] = ldx(ab + c * HW + off);   // 16 coalesced loads in flight
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float v = xin ? av[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(v, sv[t], acc[c][t]);
+      }
     }
   }
+  float* o = part + (long)blockIdx.x * 576 + wave * 144;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = acc[c][t];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane == 0) o[c * 9 + t] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float* __restrict__ part,
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float* 
 
 size_t conv1ch_wgrad_workspace_bytes(int B, int H, int W) {
   const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
-  return (size_t)B * nrowblk * 4 * 576 * sizeof(float);
+  return (size_t)B * nrowblk * 576 * sizeof(float);
 }
 
 int conv1ch_wgrad(int B, int H, int W, const void* a, int a_ctotal, int a_coff, const float* s, float* dw, int flip,
@@ -327,7 +336,7 @@ int conv1ch_wgrad(int B, int H, int W, const void* a, int a_ctotal, int a_coff, 
                        a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
   int st = check_launch("conv1ch_wgrad_kernel");
   if (st != CODON_OK) return st;
-  hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(3), dim3(256), 0, stream, ws, dw, B * nrowblk * 4, flip, 0);
+  hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(3), dim3(256), 0, stream, ws, dw, B * nrowblk, flip, 0);
   return check_launch("conv1ch_wgrad_reduce_kernel");
 }
 
