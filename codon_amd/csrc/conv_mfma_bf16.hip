@@ -20,6 +20,7 @@
 
 #include <hip/hip_bf16.h>
 
+#include <stdlib.h>
 #include <type_traits>
 
 #include "codon_common.h"
@@ -67,7 +68,9 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
   return *reinterpret_cast<u16*>(&b);
 }
 
-template <class E, int KS, int CIN, int COUT>
+// COUTB = couts per workgroup (64 or COUT): with COUTB = 64 < COUT the grid also walks cout blocks -- half the
+// accumulators and LDS per workgroup (3 workgroups per CU instead of 2), at the price of staging x twice.
+template <class E, int KS, int CIN, int COUT, int COUTB>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
   constexpr int PAD = KS / 2;
@@ -77,8 +80,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   constexpr int CK = 16, NCB = CK / 8;
   constexpr int NCHUNK = CIN / CK;
   constexpr int XS = NCB * XR * XQ;   // 16-byte elements per input buffer
-  constexpr int WS = KS * NCB * COUT; // 16-byte elements per weight stage
-  constexpr int CT = COUT / 32;
+  constexpr int WSG = KS * NCB * COUT;  // 16-byte elements per weight stage in the packed (global) image
+  constexpr int WS = KS * NCB * COUTB;  // ... of which this workgroup stages its COUTB couts
+  constexpr int CT = COUTB / 32;
+  constexpr int NCOB = COUT / COUTB;
   constexpr int NST = NCHUNK * KS;
   constexpr int XW = (CK / 2) * XR * XQ;  // 32-bit words (channel pairs) per input tile
   constexpr int XE = (XW + 255) / 256;
@@ -93,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   const int l31 = lane & 31, half = lane >> 5;
 
   unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int cob = bid % NCOB;
+  bid /= NCOB;
   const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (int)((unsigned)CIN * 2u * (unsigned)HW), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WS * 16), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WSG * 16), 0x00020000);
 
   // gather plan: word e = (channel pair cp, row r, col q), q fastest (coalesced along W)
   unsigned xoff[XE];   // unsigned element offsets: zero-extended, so loads can use SGPR base + 32-bit VGPR offset
@@ -164,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   }
 #define LOAD_W(stage_)                                                                  \
   {                                                                                     \
-    const unsigned wso_ = (unsigned)(stage_) * (unsigned)(WS * 16);                     \
+    const unsigned wso_ = (unsigned)(stage_) * (unsigned)(WSG * 16) + (unsigned)(cob * COUTB * 16); \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
-      const unsigned vo_ = (WS % 256 == 0 || tid + k * 256 < WS) ? (unsigned)(tid + k * 256) * 16u : 0u; \
+      const int e_ = tid + k * 256;   /* element e_ = (row = dx*NCB+cb, o): global element row*COUT + o */ \
+      const unsigned vo_ = (WS % 256 == 0 || e_ < WS) ? (unsigned)((e_ / COUTB) * COUT + (e_ % COUTB)) * 16u : 0u; \
       const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo_, wso_, 0);        \
       wr[k] = *reinterpret_cast<const uint4*>(&v_);                                     \
     }                                                                                   \
@@ -202,13 +210,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
     if (next_chunk) LOAD_X(chunk + 1);
 
     const uint4* xb = xs0 + (chunk & 1) * XS + (half * XR + wave * PSEG + dy) * XQ + l31;
-    const uint4* wb = ws0 + (s & 1) * WS + half * COUT + l31;
+    const uint4* wb = ws0 + (s & 1) * WS + half * COUTB + l31;
 #pragma unroll
     for (int dx = 0; dx < KS; ++dx) {
       vec8 a[CT], bv[PSEG];
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        const uint4 v = wb[dx * NCB * COUT + t * 32];
+        const uint4 v = wb[dx * NCB * COUTB + t * 32];
         a[t] = *reinterpret_cast<const vec8*>(&v);
       }
 #pragma unroll
@@ -237,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   // `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
   const int gx = tx0 + l31;
   if (gx < W) {
-    u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
-    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
+    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
     const bool relu = p.flags & CODON_CONV_RELU;
     const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
     const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
@@ -526,7 +534,7 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __rest
   }
 }
 
-template <class E, int KS, int CIN, int COUT>
+template <class E, int KS, int CIN, int COUT, int COUTB = COUT>
 static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
                          hipStream_t stream) {
   Conv16Params p;
@@ -537,11 +545,11 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + 7) / 8;
-  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch * (COUT / COUTB);
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT, COUTB>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel");
 }
 
@@ -550,7 +558,7 @@ static int conv2d_fwd_16(const codon_conv_desc* d, const void* x, const void* w,
                          hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
-    case 5128128: return launch_conv16<E, 5, 128, 128>(d, x, w, y, res, stream);
+    case 5128128: return launch_conv16<E, 5, 128, 128>(d, x, w, y, res, stream);  // COUTB = 64 measured 4 % slower
     case 5064064: return launch_conv16<E, 5, 64, 64>(d, x, w, y, res, stream);
     case 3064064: return launch_conv16<E, 3, 64, 64>(d, x, w, y, res, stream);
     case 3128064: return launch_conv16<E, 3, 128, 64>(d, x, w, y, res, stream);

@@ -14,8 +14,14 @@
 //
 // Structure = conv_mfma_bf16.hip (channel-blocked LDS images, (chunk of 16 channels, filter row) stages, next stage
 // prefetched to registers before the MFMAs and converted/written after them), with two images per operand.
-// Workgroup tile: 8 rows x 32 pixels x 64 couts (blockIdx also walks cout halves when COUT = 128) so that
-// xs (hi+lo, single-buffered) + ws (hi+lo, double-buffered) = 67.6 KB -> two workgroups per CU.
+// Workgroup tile: 8 rows x 32 pixels x 64 couts, 4 waves, xs (hi+lo, single-buffered) + ws (hi+lo, double-buffered)
+// = 67.6 KB -> two workgroups per CU; the 5x5 128->128 convs use 16 x 32 x 128, 8 waves, 126 KB (one workgroup per
+// CU, 120 MFMAs per wave per barrier).
+// Measured (rocprofv3 PMC, profiles/): the matrix pipes are 75 % busy in CYCLES on the wide kernel, but the chip
+// holds only ~1.59 GHz under this load (GRBM_GUI_ACTIVE / 8 / time), so 1 326-1 438 TF of issued f16 MFMA is what
+// 75 % buys: the kernel is power/clock-limited, not stall-limited (MI355X_MICROARCH.md "DVFS give-back").
+
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -46,11 +52,14 @@ __device__ __forceinline__ u16 f2h_bits(float f) {
 }
 __device__ __forceinline__ float h2f_bits(u16 v) { return (float)*reinterpret_cast<const _Float16*>(&v); }
 
-template <int KS, int CIN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Params p) {
+// COUTB couts and NW waves (NW*2 pixel rows) per workgroup:  <64, 4> = 8x32x64 tile, 68.6 KB LDS, 2 workgroups/CU;
+// <128, 8> = 16x32x128 tile, 126 KB LDS, one 8-wave workgroup per CU with 120 MFMAs per wave per barrier.
+template <int KS, int CIN, int COUTB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS3Params p) {
+  constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
-  constexpr int PSEG = 2, COUTB = 64, CT = 2;
-  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int PSEG = 2, CT = COUTB / 32;
+  constexpr int TW = 32, TH = NW * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = 16, NCB = 2;
   constexpr int NCHUNK = CIN / CK;
@@ -59,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
   constexpr int WS = 2 * WS1;                // hi + lo
   constexpr int NST = NCHUNK * KS;
   constexpr int XW = (CK / 2) * XR * XQ;     // channel-pair words per x tile
-  constexpr int XE = (XW + 255) / 256;
-  constexpr int WE = (WS + 255) / 256;
+  constexpr int XE = (XW + NT - 1) / NT;
+  constexpr int WE = (WS + NT - 1) / NT;
 
   __shared__ uint4 lds[2 * XS + 2 * WS];
   uint4* const xh = lds;            // x hi image
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
   const long HW = (long)H * W;
 
   const float* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
-  const uint4* __restrict__ wg = p.w + (long)cob * NST * WS;
+  const uint4* __restrict__ wg = p.w + (long)cob * NST * WS;   // packed per COUTB-cout block
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (int)((unsigned)CIN * 4u * (unsigned)HW), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WS * 16), 0x00020000);
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
   unsigned xmask = 0;
 #pragma unroll
   for (int k = 0; k < XE; ++k) {
-    const int e = tid + k * 256;
+    const int e = tid + k * NT;
     const int cp = e / (XR * XQ);
     const int rem = e - cp * (XR * XQ);
     const int r = rem / XQ, q = rem - r * XQ;
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
     unsigned* dh_ = reinterpret_cast<unsigned*>(xh);                                     \
     unsigned* dl_ = reinterpret_cast<unsigned*>(xl);                                     \
     _Pragma("unroll") for (int k = 0; k < XE; ++k)                                       \
-        if (XW % 256 == 0 || tid + k * 256 < XW) {                                       \
+        if (XW % NT == 0 || tid + k * NT < XW) {                                         \
           const bool m_ = (xmask >> k) & 1u;                                             \
           const float a_ = m_ ? x0[k] : 0.f, b_ = m_ ? x1[k] : 0.f;                      \
           const u16 ah_ = f2h_bits(a_), bh_ = f2h_bits(b_);                              \
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
   {                                                                                      \
     const unsigned wso_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                     \
-      const unsigned vo_ = (WS % 256 == 0 || tid + k * 256 < WS) ? (unsigned)(tid + k * 256) * 16u : 0u; \
+      const unsigned vo_ = (WS % NT == 0 || tid + k * NT < WS) ? (unsigned)(tid + k * NT) * 16u : 0u; \
       const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo_, wso_, 0);         \
       wr[k] = *reinterpret_cast<const uint4*>(&v_);                                      \
     }                                                                                    \
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
   {                                                                                      \
     uint4* dst_ = ws0 + (buf_) * WS;                                                     \
     _Pragma("unroll") for (int k = 0; k < WE; ++k)                                       \
-        if (WS % 256 == 0 || tid + k * 256 < WS) dst_[tid + k * 256] = wr[k];            \
+        if (WS % NT == 0 || tid + k * NT < WS) dst_[tid + k * NT] = wr[k];               \
   }
 
   f32x16 acc[PSEG][CT];
@@ -261,32 +270,33 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32x3_kernel(const ConvS3Par
 }
 
 // OIHW fp32 -> [cout64 block][chunk][dy][part][dx][cb (2)][64 cout][8 ch] fp16, scaled by 2^10, split hi/lo
-__global__ void pack_weight_f32x3_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks) {
+__global__ void pack_weight_f32x3_kernel(const float* __restrict__ w, u16* __restrict__ out, int cout, int cin, int ks,
+                                         int coutb) {
   const long n = (long)cout * cin * ks * ks;  // elements per part
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long t = i;
     const int j = t % 8; t /= 8;
-    const int o = t % 64; t /= 64;
+    const int o = t % coutb; t /= coutb;
     const int cb = t % 2; t /= 2;
     const int dx = t % ks; t /= ks;
     const int dy = t % ks; t /= ks;
     const int nchunk = cin / 16;
     const int chunk = t % nchunk; t /= nchunk;
     const int cob = (int)t;
-    const int ci = chunk * 16 + cb * 8 + j, co = cob * 64 + o;
+    const int ci = chunk * 16 + cb * 8 + j, co = cob * coutb + o;
     const float v = w[(((long)co * cin + ci) * ks + dy) * ks + dx] * (float)(1 << F3_WSCALE_LOG2);
     const u16 hi = f2h_bits(v);
     const u16 lo = f2h_bits(v - h2f_bits(hi));
     // destination: stage (cob, chunk, dy) holds [part][dx][cb][o][j]
     const long stage = ((long)cob * nchunk + chunk) * ks + dy;
-    const long within = (((long)dx * 2 + cb) * 64 + o) * 8 + j;
-    const long part = (long)ks * 2 * 64 * 8;
+    const long within = (((long)dx * 2 + cb) * coutb + o) * 8 + j;
+    const long part = (long)ks * 2 * coutb * 8;
     out[stage * 2 * part + within] = hi;
     out[stage * 2 * part + part + within] = lo;
   }
 }
 
-template <int KS, int CIN>
+template <int KS, int CIN, int COUTB, int NW>
 static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, float* y, const float* res,
                      hipStream_t stream) {
   ConvS3Params p;
@@ -296,15 +306,21 @@ static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, fl
   p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = d->r_ctotal * HW;
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
   p.tiles_x = (d->width + 31) / 32;
-  p.tiles_y = (d->height + 7) / 8;
-  p.ncob = d->cout / 64;
+  p.tiles_y = (d->height + 2 * NW - 1) / (2 * NW);
+  p.ncob = d->cout / COUTB;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch * p.ncob;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
-  hipLaunchKernelGGL((conv_mfma_f32x3_kernel<KS, CIN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_f32x3_kernel<KS, CIN, COUTB, NW>), dim3((unsigned)nblk), dim3(NW * 64), 0, stream, p);
   return check_launch("conv_mfma_f32x3_kernel");
 }
+
+// couts per workgroup (also the block size of the packed weight image): 128 for the 5x5 128->128 convs
+static int f32x3_coutb_for(int ks, int cin, int cout) {
+  return (ks == 5 && cin == 128 && cout == 128) ? 128 : 64;   // wide tile measured 7 % faster there
+}
+static int f32x3_coutb(const codon_conv_desc* d) { return f32x3_coutb_for(d->ksize, d->cin, d->cout); }
 
 bool conv_f32x3_supported(const codon_conv_desc* d) {
   return (d->ksize == 3 || d->ksize == 5) && (d->cin == 64 || d->cin == 128) && (d->cout == 64 || d->cout == 128);
@@ -313,11 +329,14 @@ bool conv_f32x3_supported(const codon_conv_desc* d) {
 int conv2d_fwd_f32x3(const codon_conv_desc* d, const float* x, const void* w, float* y, const float* res,
                      hipStream_t stream) {
   const int key = d->ksize * 1000 + d->cin;
+  if (f32x3_coutb(d) == 128) {   // 128-cout convs (conv3/6/10): one 8-wave 16x32x128 workgroup per CU
+    if (key == 5128) return launch_s3<5, 128, 128, 8>(d, x, w, y, res, stream);
+  }
   switch (key) {
-    case 5128: return launch_s3<5, 128>(d, x, w, y, res, stream);
-    case 5064: return launch_s3<5, 64>(d, x, w, y, res, stream);
-    case 3064: return launch_s3<3, 64>(d, x, w, y, res, stream);
-    case 3128: return launch_s3<3, 128>(d, x, w, y, res, stream);
+    case 5128: return launch_s3<5, 128, 64, 4>(d, x, w, y, res, stream);
+    case 5064: return launch_s3<5, 64, 64, 4>(d, x, w, y, res, stream);
+    case 3064: return launch_s3<3, 64, 64, 4>(d, x, w, y, res, stream);
+    case 3128: return launch_s3<3, 128, 64, 4>(d, x, w, y, res, stream);
     default:
       set_error("conv2d_fwd: no f16x3 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
       return CODON_ERR_UNSUPPORTED;
@@ -327,7 +346,8 @@ int conv2d_fwd_f32x3(const codon_conv_desc* d, const float* x, const void* w, fl
 int pack_weight_f32x3(const float* w, void* out, int cout, int cin, int ks, hipStream_t stream) {
   const long n = (long)cout * cin * ks * ks;
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(pack_weight_f32x3_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks);
+  hipLaunchKernelGGL(pack_weight_f32x3_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)out, cout, cin, ks,
+                     f32x3_coutb_for(ks, cin, cout));
   return check_launch("pack_weight_f32x3_kernel");
 }
 
