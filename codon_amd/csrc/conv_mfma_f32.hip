@@ -40,6 +40,10 @@ struct ConvParams {
   long x_base, y_base, r_base;  // channel offset * H * W
   int tiles_x, tiles_y, nblk;
   int flags;
+  // FUSE only: the chained 1x1 (128 -> 64) applied to the tile while it is still in the accumulators
+  const float* w2;  // [t2][t][lane][16]: W1[t2*32 + (lane&31)][t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
+  float* y2;
+  long y2_img, y2_base;
 };
 
 template <int KS, int CIN>
@@ -48,7 +52,7 @@ struct ConvCfg {
   static constexpr int NCHUNK = CIN / CK;
 };
 
-template <int KS, int CIN, int COUT, int PSEG>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams p) {
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = 4 * PSEG;
@@ -191,6 +195,78 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   // variants: inside a variant the residual / accumulate loads of a tile are unconditional and issued back to
   // back (a per-element `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
   const int gx = tx0 + l31;
+  if constexpr (FUSE) {
+    // Chained 1x1: the D layout of the 32x32 MFMA (lane = pixel l&31, register r = channel (r&3)+8(r>>2)+4(l>>5))
+    // IS a B operand of the next MFMA for the channel pair {c, c+4}: lanes 0-31 carry k = 0, lanes 32-63 k = 1 of
+    // the same 32 pixels.  So Y2[co2][pix] = sum_c W1[co2][c] relu(acc)[c][pix] runs straight from the accumulator
+    // registers -- 64 MFMAs per 32 output channels and pixel row, no LDS round trip, and the 128-channel
+    // intermediate never has to reach HBM (p.y == nullptr).  W1 is pre-permuted to that k order by the packer.
+    static_assert(!FUSE || COUT == 128, "chained 1x1 is 128 -> 64");
+    const bool relu = p.flags & CODON_CONV_RELU;
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][t][r] = relu ? fmaxf(acc[i][t][r], 0.f) : acc[i][t][r];
+    if (p.y && gx < W) {
+      float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+#pragma unroll
+          for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + (long)gy * W + gx] = acc[i][t][r];
+        }
+      }
+    }
+    const float4* __restrict__ w2 = reinterpret_cast<const float4*>(p.w2) + lane * 4;
+    float* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
+    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+#pragma unroll 1
+    for (int t2 = 0; t2 < 2; ++t2) {
+      f32x16 d[PSEG];
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[i][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        float4 a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = w2[((t2 * CT + t) * 64) * 4 + q];
+        const float* a = reinterpret_cast<const float*>(a4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i)
+            d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[i][t][r], d[i], 0, 0, 0);
+      }
+      if (gx < W) {
+#pragma unroll
+        for (int i = 0; i < PSEG; ++i) {
+          const int gy = ty0 + wave * PSEG + i;
+          if (gy < H) {
+            const long pix = (long)gy * W + gx;
+            if (rg) {
+              float rv[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] + rv[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r];
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (gx < W) {
     float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
     const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
@@ -260,6 +336,21 @@ __global__ void pack_weight_f32_kernel(const float* __restrict__ w, float* __res
   }
 }
 
+// OIHW (64,128,1,1) fp32 -> the chained-1x1 A-operand image [t2][t][lane][r]
+__global__ void pack_chain1x1_f32_kernel(const float* __restrict__ w, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 64 * 128 values
+  if (i >= 64 * 128) return;
+  const int r = i & 15, lane = (i >> 4) & 63, t = (i >> 10) & 3, t2 = i >> 12;
+  const int co2 = t2 * 32 + (lane & 31);
+  const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  out[i] = w[co2 * 128 + c];
+}
+
+int pack_chain1x1_f32(const float* w, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_chain1x1_f32_kernel, dim3(32), dim3(256), 0, stream, w, out);
+  return check_launch("pack_chain1x1_f32_kernel");
+}
+
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_conv(const codon_conv_desc* d, const float* x, const float* w, float* y,
                        const float* res, hipStream_t stream) {
@@ -276,11 +367,35 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+  p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel");
 }
 
 int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
+
+// d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1
+int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* w_chain,
+                          const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+  CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
+  constexpr int TH = 8;
+  ConvParams p;
+  p.x = x; p.w = w; p.y = y; p.res = res ? (const float*)res->data : nullptr;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = res ? res->ctotal * HW : 0;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = res ? res->coff * HW : 0;
+  p.w2 = w_chain; p.y2 = (float*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + TH - 1) / TH;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_mfma_f32_kernel<fused 1x1>");
+}
 
 int conv2d_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* res,
                    hipStream_t stream) {

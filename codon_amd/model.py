@@ -309,10 +309,13 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         self.relu = nn.ReLU()
         self._pack_cache: Dict[str, tuple] = {}
         self.compute_dtype: Optional[torch.dtype] = None
+        self.conv_precision: str = "exact"
 
     set_compute_dtype = _CODONBase.set_compute_dtype
+    set_conv_precision = _CODONBase.set_conv_precision
     _act_dtype = _CODONBase._act_dtype
     _packed = _CODONBase._packed
+    _split = _CODONBase._split
     __getstate__ = _CODONBase.__getstate__
 
     def forward(self, x, y):
@@ -329,18 +332,19 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=x.device)
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
         P = self._packed
+        S3, S5 = self._split(3), self._split(5)
         t64, stage, r2, oc = new(64), new(128), new(128), new(128)
 
         def stream(img, w_in, n_ci, c3x3, c5x5, first5, n3, nconf, out_slice):      # :53-74
             inputs = new(64)
             ops.stem(img, f32(getattr(self, w_in).weight), Slice(t64))
-            ops.conv2d(Slice(t64), P(n_ci), Slice(inputs), 3, relu=True)
+            ops.conv2d(Slice(t64), P(n_ci), Slice(inputs), 3, relu=True, f16x3=S3)
             cur = Slice(inputs)
             for i in range(5):
                 a, b = (c5x5, c3x3) if first5 else (c3x3, c5x5)
-                ops.conv2d(cur, P(a), Slice(stage, 0, 64), 5 if first5 else 3, relu=True)
-                ops.conv2d(cur, P(b), Slice(stage, 64, 64), 3 if first5 else 5, relu=True)
-                ops.conv2d(Slice(stage), P(n3), Slice(r2), 5, relu=True)
+                ops.conv2d(cur, P(a), Slice(stage, 0, 64), 5 if first5 else 3, relu=True, f16x3=S5 if first5 else S3)
+                ops.conv2d(cur, P(b), Slice(stage, 64, 64), 3 if first5 else 5, relu=True, f16x3=S3 if first5 else S5)
+                ops.conv2d(Slice(stage), P(n3), Slice(r2), 5, relu=True, f16x3=S5)
                 dst = out_slice if i == 4 else Slice(new(64))
                 ops.conv2d(Slice(r2), P(nconf), dst, 1, residual=Slice(inputs))     # confuse(...) + inputs
                 cur = dst
@@ -348,15 +352,15 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         stream(x, "input", "conv_input", "conv1", "conv2", False, "conv3", "confuse", Slice(oc, 0, 64))
         stream(y, "input_c", "conv_input_c", "conv5", "conv4", True, "conv6", "confuse_c", Slice(oc, 64, 64))
         fuse, fA = new(64), new(64)
-        ops.conv2d(Slice(oc), P("conv7"), Slice(fuse), 3, relu=True)                # :76-77
+        ops.conv2d(Slice(oc), P("conv7"), Slice(fuse), 3, relu=True, f16x3=S3)                # :76-77
         f = fuse
         for _ in range(3):                                                          # :79-85
-            ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True)
-            ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True)
-            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True)
+            ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True, f16x3=S5)
+            ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True, f16x3=S3)
+            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True, f16x3=S5)
             ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))
             f = fA
-        ops.conv2d(Slice(f), P("conv11"), Slice(t64), 3, relu=True)                 # :87
+        ops.conv2d(Slice(f), P("conv11"), Slice(t64), 3, relu=True, f16x3=S3)                 # :87
         out = torch.empty_like(x)
         ops.head(Slice(t64), f32(self.output.weight), x, out)                       # :88-89
         return out if idt == torch.float32 else out.to(idt)

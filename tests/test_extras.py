@@ -64,6 +64,11 @@ def test_rmcr_ablation_matches_golden():
         with torch.no_grad():
             o = m(x.cuda(), y.cuda())
         assert rmse(o.cpu(), z[f"{nm}.out"]) <= 1e-4 and rel_rmse(o.cpu(), z[f"{nm}.out"]) < 1e-5
+        m.set_conv_precision("f16x3")                      # opt-in split-precision convs: same bar
+        with torch.no_grad():
+            o3 = m(x.cuda(), y.cuda())
+        m.set_conv_precision("exact")
+        assert rmse(o3.cpu(), z[f"{nm}.out"]) <= 1e-4 and rel_rmse(o3.cpu(), z[f"{nm}.out"]) < 1e-5
 
 
 @pytest.mark.gpu
