@@ -235,7 +235,8 @@ def main():
         maps_s = world * B * a.steps / dt
         ev = prof["events"]
         kms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
-        kflop = 2.0 * CONV5_128_MAC_PER_PIXEL * P
+        chained = bool(prof.get("chained"))       # the launch also carries the 128->64 1x1 (+2 % MACs)
+        kflop = 2.0 * (CONV5_128_MAC_PER_PIXEL + (128 * 64 if chained else 0)) * P
         ach = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         step_s = dt / a.steps
         res = {
@@ -249,13 +250,15 @@ def main():
                        "parallelism": f"dp{world}: images sharded across ranks, no collective in forward",
                        "weights": "reference init rule (He-normal convs, default CAC), torch.manual_seed(0)"},
             "roofline": {"bound": "mfma", "kernel": ("conv_mfma_f32x3_kernel<5,128>" if split else
-                                                      f"conv_mfma_{a.dtype}_kernel<5,128,128>") + " (conv3/conv6/conv10)",
+                                                      f"conv_mfma_{a.dtype}_kernel<5,128,128>") +
+                                   (" + register-chained 1x1 128->64 (conv3+confuse / conv6+confuse_c / conv10+confuse_fuse)"
+                                    if chained else " (conv3/conv6/conv10)"),
                          "achieved": ach * (3 if split else 1), "peak": PEAK_BF16_MFMA_TFLOPS if split else peak_mfma,
                          "unit": "TFLOP/s", "frac": ach * (3 if split else 1) / (PEAK_BF16_MFMA_TFLOPS if split else peak_mfma),
                          "note": "f16x3: achieved counts the 3 f16 MFMA products actually issued per fp32 product" if split else None,
                          "traffic": None if bf16 else pmc_traffic("codon::conv_mfma_f32_kernel<5, 128, 128", B, H, W),
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                         "alg_bytes_per_launch": 2 * 128 * esize * P,
+                         "alg_bytes_per_launch": (128 + 64 if chained else 2 * 128) * esize * P,
                          "launches_timed": len(ev), "avg_launch_ms": kms,
                          "flop_per_launch": kflop},
             "whole_forward": {"tflops": FLOP_PER_PIXEL_FWD * P / step_s / 1e12,

@@ -19,7 +19,7 @@ LIB_NAME = "libcodon_hip.so"
 OK = 0
 F32, BF16, F16 = 0, 1, 2
 CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU, CONV_F16X3 = 1, 2, 4, 8, 16
-PACK_FWD, PACK_DGRAD, PACK_FWD_F16X3 = 0, 1, 2
+PACK_FWD, PACK_DGRAD, PACK_FWD_F16X3, PACK_CHAIN1X1 = 0, 1, 2, 3
 
 
 class ConvDesc(C.Structure):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "codon_conv_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
     "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "codon_conv_chain1x1_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P]),
     "codon_conv_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "codon_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _I, _P]),
     "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),

@@ -34,6 +34,9 @@ int conv2d_wgrad_f32(const codon_conv_desc*, const float*, const float*, float*,
 size_t conv_wgrad_bf16_workspace_bytes(const codon_conv_desc*);
 int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
+int pack_chain1x1_f32(const float*, float*, hipStream_t);
+int conv_chain1x1_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, const codon_tensor*,
+                          const codon_tensor*, hipStream_t);
 bool conv_f32x3_supported(const codon_conv_desc*);
 int conv2d_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const float*, hipStream_t);
 int pack_weight_f32x3(const float*, void*, int, int, int, hipStream_t);
@@ -101,6 +104,12 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
                   CODON_ERR_UNSUPPORTED, "conv_pack_weight: f16x3 packing needs fp32, k in {3,5}, cin%%16==0, cout%%64==0");
     return pack_weight_f32x3(w_oihw, w_packed, cout, cin, ksize, (hipStream_t)stream);
   }
+  if (mode == CODON_PACK_CHAIN1X1) {
+    CODON_REQUIRE(ksize == 1 && cin == 128 && cout == 64, CODON_ERR_UNSUPPORTED,
+                  "conv_pack_weight: CHAIN1X1 packs the (64,128,1,1) weights only");
+    CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: CHAIN1X1 dtype %d", dtype);
+    return pack_chain1x1_f32(w_oihw, (float*)w_packed, (hipStream_t)stream);
+  }
   CODON_REQUIRE(mode == CODON_PACK_FWD || mode == CODON_PACK_DGRAD, CODON_ERR_BAD_ARG, "conv_pack_weight: mode %d", mode);
   const int kin = mode == CODON_PACK_DGRAD ? cout : cin;
   CODON_REQUIRE(cout > 0 && cin > 0 && kin % conv_ck(ksize) == 0, CODON_ERR_UNSUPPORTED,
@@ -140,6 +149,29 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
   }
   return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
                         (hipStream_t)stream);
+}
+
+int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y, const void* w_chain,
+                            const codon_tensor* out, const codon_tensor* residual, codon_stream_t stream) {
+  CODON_REQUIRE(d && x && w_packed && w_chain && out && out->data, CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: bad shape %dx%dx%d",
+                d->batch, d->height, d->width);
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_fwd: input slice outside its buffer");
+  CODON_REQUIRE(!y || (d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal), CODON_ERR_BAD_ARG,
+                "conv_chain1x1_fwd: intermediate slice outside its buffer");
+  CODON_REQUIRE(out->coff >= 0 && out->coff + 64 <= out->ctotal, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_fwd: output slice outside its buffer");
+  CODON_REQUIRE(!residual || (residual->data && residual->coff >= 0 && residual->coff + 64 <= residual->ctotal),
+                CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: residual slice outside its buffer");
+  CODON_REQUIRE((d->flags & ~(CODON_CONV_RELU | CODON_CONV_F16X3)) == 0, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_fwd: only RELU / F16X3 flags apply to the 5x5 stage");
+  CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)w_chain % 16) == 0, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_fwd: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_F32 && !(d->flags & CODON_CONV_F16X3), CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: dtype %d flags %d not supported", d->dtype, d->flags);
+  return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out,
+                               residual, (hipStream_t)stream);
 }
 
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {

@@ -207,6 +207,18 @@ class _CODONBase(nn.Module):
         def conv(xs, name, ys, k, **kw):   # one MFMA conv; 3x3 / 5x5 take the split-precision kernel when opted in
             ops.conv2d(xs, P(name), ys, k, f16x3=self._split(k), **kw)
 
+        chain = adt == torch.float32 and not self._split(5)
+
+        def conv5_1x1(xs, name5, name1, mid, ys, residual=None):
+            """ys = conv1x1(relu(conv5x5(xs))) [+ residual]; mid = relu(conv5x5(xs)) is only materialised when the
+            backward needs it (one launch: the 1x1 runs from the 5x5's accumulators)."""
+            if chain:
+                ops.conv_chain1x1(xs, P(name5), P(name1, L.PACK_CHAIN1X1), ys, mid=mid if keep else None,
+                                  residual=residual)
+            else:
+                conv(xs, name5, mid, 5, relu=True)
+                ops.conv2d(mid, P(name1), ys, 1, residual=residual)
+
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
@@ -239,13 +251,11 @@ class _CODONBase(nn.Module):
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
             conv(out, "conv1", Slice(stage, 0, 64), 3, relu=True)
             conv(out, "conv2", Slice(stage, 64, 64), 5, relu=True)
-            conv(Slice(stage), "conv3", Slice(r2), 5, relu=True)          # :81
-            conv(Slice(r2), "confuse", pre, 1)                            # :84
+            conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre)   # :81,84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
             conv(out_c, "conv4", Slice(stage_c, 0, 64), 5, relu=True)
             conv(out_c, "conv5", Slice(stage_c, 64, 64), 3, relu=True)
-            conv(Slice(stage_c), "conv6", Slice(r2_c), 5, relu=True)      # :82
-            conv(Slice(r2_c), "confuse_c", pre_c, 1)                      # :83
+            conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c)   # :82,83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
             ops.cac_stats(pre_c, pre, pooled, partials)
@@ -273,8 +283,7 @@ class _CODONBase(nn.Module):
                 stage, r2, fA = new(128), new(128), new(64)
             conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
             conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
-            conv(Slice(stage), "conv10", Slice(r2), 5, relu=True)         # :126
-            ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))  # :127-128
+            conv5_1x1(Slice(stage), "conv10", "confuse_fuse", Slice(r2), Slice(fA), residual=Slice(fuse))  # :126-128
             if keep:
                 save[f"trunk{i}"] = dict(x=f, stage=stage, r2=r2)
             f = fA

@@ -120,6 +120,34 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
             prof["events"].append((e0, e1))
 
 
+def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: Slice, mid: Optional[Slice] = None,
+                  residual: Optional[Slice] = None, f16x3: bool = False):
+    """out = conv1x1(relu(conv5x5(x))) [+ residual] in one launch (the 1x1 runs from the 5x5's accumulators);
+    mid, when given, also receives relu(conv5x5(x)) (training saves it)."""
+    lib = L.load()
+    dev = _dev(x.buf, w_packed, w_chain, out.buf, mid.buf if mid else None, residual.buf if residual else None)
+    B, _, H, W = x.buf.shape
+    assert out.c == 64 and out.buf.shape[0] == B and out.buf.shape[2:] == x.buf.shape[2:]
+    assert out.buf.dtype == x.buf.dtype and (mid is None or (mid.c == 128 and mid.buf.shape[2:] == x.buf.shape[2:]))
+    assert residual is None or (residual.c == 64 and residual.buf.shape[2:] == x.buf.shape[2:])
+    flags = L.CONV_RELU | (L.CONV_F16X3 if f16x3 else 0)
+    d = L.ConvDesc(B, H, W, x.c, 128, 5, x.ctotal, x.coff, mid.ctotal if mid else 128, mid.coff if mid else 0,
+                   0, 0, flags, _dt(x.buf))
+    prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (5, x.c, 128)) else None
+    with torch.cuda.device(dev):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+        ot, rt = out.ct(), (residual.ct() if residual else None)
+        L.check(lib.codon_conv_chain1x1_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed), _ptr(mid.buf if mid else None),
+                                            _ptr(w_chain), C.byref(ot), C.byref(rt) if rt is not None else None,
+                                            _stream(dev)), "conv_chain1x1_fwd")
+        if prof is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            prof["events"].append((e0, e1))
+            prof["chained"] = True
+
+
 def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: bool = False):
     """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy."""
     lib = L.load()

@@ -49,7 +49,7 @@ enum {
                                   product; |activations| < 65504).  w_packed must come from CODON_PACK_FWD_F16X3. */
 };
 
-enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2 };
+enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2, CODON_PACK_CHAIN1X1 = 3 };
 
 /* One stride-1, "same"-padded, bias-free 2-D convolution (every nn.Conv2d of
  * CODON_X4/CODON_x4.py:24-47 has stride 1, padding k//2, bias=False). */
@@ -83,12 +83,26 @@ size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, 
 /* w_oihw: (cout, cin, k, k) fp32 contiguous (the nn.Conv2d.weight layout).
  * mode CODON_PACK_FWD  : pack for y = conv(x, w)
  * mode CODON_PACK_DGRAD: pack the spatially flipped, in/out-transposed filter so that the SAME
- *                        forward kernel computes dL/dx = conv(dL/dy, w') (cin/cout swap roles). */
+ *                        forward kernel computes dL/dx = conv(dL/dy, w') (cin/cout swap roles).
+ * mode CODON_PACK_CHAIN1X1: (64,128,1,1) only -- the register-chained 1x1 of codon_conv_chain1x1_fwd. */
 int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, int32_t cin,
                            int32_t ksize, int32_t mode, int32_t dtype, codon_stream_t stream);
 
 int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
                      const void* residual, codon_stream_t stream);
+
+/* conv5x5(128 -> 128) + ReLU and the 1x1 conv (128 -> 64) [+ residual] that consumes it, in ONE launch:
+ *   confuse(relu(conv3(.))) / confuse_c(relu(conv6(.))) / torch.add(confuse_fuse(relu(conv10(.))), fuse)
+ *   /root/reference/CODON_X4/CODON_x4.py:81-84,125-128.
+ * The MFMA accumulator layout of the 5x5 tile is already a B operand of the 1x1's MFMAs, so the 1x1 runs from
+ * registers and the 128-channel intermediate need not reach HBM: y may be NULL (inference); when given (training
+ * saves it) it receives relu(conv5x5) exactly as codon_conv2d_fwd would write it.
+ * d: the 5x5 conv (flags: CODON_CONV_RELU [| CODON_CONV_F16X3]; r_* ignored).  w_chain: the (64,128,1,1) weight
+ * packed with mode CODON_PACK_CHAIN1X1 (same dtype; 64*128 elements).  out / residual: 64-channel slices of
+ * d->dtype; residual may be NULL. */
+int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
+                            const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
+                            codon_stream_t stream);
 
 /* dL/dw (cout, cin, k, k) fp32 = sum over b,h,w of gy[b,co,h,w] * x[b,ci,h+dy-p,w+dx-p]: what autograd
  * computes for the nn.Conv2d weights (the reference has no explicit backward).

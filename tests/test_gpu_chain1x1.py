@@ -1,0 +1,64 @@
+"""conv5x5(128->128)+ReLU with the 1x1 (128->64) [+ residual] chained from the accumulators
+(codon_conv_chain1x1_fwd) against the same two ops in torch CPU fp32 and against the two separate HIP launches."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_kernels import _dev, _rand
+from tests.util import rel_rmse
+
+SHAPES = [(2, 19, 45), (1, 8, 32), (1, 33, 70), (1, 1, 1), (1, 5, 3), (3, 16, 64)]
+
+
+def _case(shape):
+    B, H, W = shape
+    x = _rand((B, 128, H, W), 11)
+    w5 = _rand((128, 128, 5, 5), 12, scale=(2.0 / (25 * 128)) ** 0.5)
+    w1 = _rand((64, 128, 1, 1), 13, scale=(1.0 / 128) ** 0.5)
+    r = _rand((B, 64, H, W), 14)
+    mid = F.relu(F.conv2d(x, w5, None, 1, 2))
+    return x, w5, w1, r, mid, F.conv2d(mid, w1)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_chain1x1_f32_vs_torch(shape):
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x, w5, w1, r, mid_ref, out_ref = _case(shape)
+    xd = x.to(dev)
+    wp = ops.packed_weight(w5.to(dev))
+    wc = ops.packed_weight(w1.to(dev), L.PACK_CHAIN1X1)
+    # outputs land in channels [64,128) of a wider buffer (the Fcat layout); the rest must stay untouched
+    out = torch.full((B, 128, H, W), float("nan"), device=dev)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(out, 64, 64))
+    assert torch.isnan(out[:, :64]).all()
+    assert rel_rmse(out[:, 64:].cpu(), out_ref) < 2e-6
+    # + residual, and the intermediate materialised (what training saves)
+    mid = torch.full((B, 128, H, W), float("nan"), device=dev)
+    o2 = torch.full((B, 64, H, W), float("nan"), device=dev)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(o2), mid=Slice(mid), residual=Slice(r.to(dev)))
+    assert rel_rmse(o2.cpu(), out_ref + r) < 2e-6
+    assert rel_rmse(mid.cpu(), mid_ref) < 2e-6
+    # the two separate launches: the intermediate is bit-identical, the 1x1 differs by summation order only
+    m2 = torch.empty_like(mid)
+    ops.conv2d(Slice(xd), wp, Slice(m2), 5, relu=True)
+    assert torch.equal(m2, mid)
+    o3 = torch.empty_like(o2)
+    ops.conv2d(Slice(m2), ops.packed_weight(w1.to(dev)), Slice(o3), 1, residual=Slice(r.to(dev)))
+    assert rel_rmse(o2.cpu(), o3.cpu()) < 1e-6
+
+
+def test_chain1x1_rejects_bad_arguments():
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    x = torch.zeros((1, 64, 4, 4), device=dev)
+    w = torch.zeros(64 * 64 * 25, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.conv_chain1x1(Slice(x), w, w, Slice(torch.zeros((1, 64, 4, 4), device=dev)))     # cin must be 128
+    with pytest.raises(RuntimeError):
+        ops.packed_weight(torch.zeros((64, 64, 1, 1), device=dev), L.PACK_CHAIN1X1)           # (64,128,1,1) only
