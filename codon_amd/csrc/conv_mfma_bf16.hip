@@ -59,6 +59,10 @@ struct Conv16Params {
   long x_base, y_base, r_base;
   int tiles_x, tiles_y, nblk;
   int flags;
+  // FUSE only: chained 1x1 (128 -> 64) from the accumulators, see conv_mfma_f32.hip
+  const uint4* w2;  // [t2][t][g][lane] x 16 B: W1[t2*32 + (lane&31)][t*32 + 16g + (j&3) + 8(j>>2) + 4(lane>>5)], j = 0..7
+  u16* y2;
+  long y2_img, y2_base;
 };
 
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
@@ -70,7 +74,7 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
 
 // COUTB = couts per workgroup (64 or COUT): with COUTB = 64 < COUT the grid also walks cout blocks -- half the
 // accumulators and LDS per workgroup (3 workgroups per CU instead of 2), at the price of staging x twice.
-template <class E, int KS, int CIN, int COUT, int COUTB>
+template <class E, int KS, int CIN, int COUT, int COUTB, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
   constexpr int PAD = KS / 2;
@@ -244,6 +248,92 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   // residual / accumulate load is unconditional and the 16 loads of a tile are issued back to back (a per-element
   // `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
   const int gx = tx0 + l31;
+  if constexpr (FUSE) {
+    // Chained 1x1 from the accumulators: registers 8g..8g+7 of a 32x32 D tile, rounded to 16 bits (exactly the
+    // values the unfused path would have stored and reloaded), are the 8 k-values a lane feeds to the next
+    // 32x32x16 MFMA as its B operand -- channels t*32 + 16g + {0,1,2,3,8,9,10,11} + 4*half; the packer permutes
+    // W1 to that k order.  16 MFMAs per pixel row instead of a second kernel and an HBM round trip.
+    static_assert(!FUSE || (COUT == 128 && COUTB == 128), "chained 1x1 is 128 -> 64");
+    const bool relu = p.flags & CODON_CONV_RELU;
+    vec8 pk[PSEG][CT][2];
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          u16 h8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = acc[i][t][8 * g + j];
+            h8[j] = E::from_f32(relu ? fmaxf(v, 0.f) : v);
+          }
+          pk[i][t][g] = *reinterpret_cast<const vec8*>(h8);
+        }
+    if (p.y && gx < W) {
+      u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+#pragma unroll
+          for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const u16* h8 = reinterpret_cast<const u16*>(&pk[i][t][g]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                yg[(t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * half) * HW + (long)gy * W + gx] = h8[j];
+            }
+        }
+      }
+    }
+    const uint4* __restrict__ w2 = p.w2 + lane;
+    u16* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
+    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    f32x16 d[2][PSEG];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t2][i][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint4 av = w2[((t2 * CT + t) * 2 + g) * 64];
+          const vec8 a = *reinterpret_cast<const vec8*>(&av);
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i) d[t2][i] = E::mfma(a, pk[i][t][g], d[t2][i]);
+        }
+    }
+    if (gx < W) {
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const int gy = ty0 + wave * PSEG + i;
+        if (gy < H) {
+          const long pix = (long)gy * W + gx;
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            if (rg) {
+              float rv[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = E::to_f32(rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = E::from_f32(d[t2][i][r] + rv[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = E::from_f32(d[t2][i][r]);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (gx < W) {
     u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
     const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
@@ -534,6 +624,53 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, u16* __rest
   }
 }
 
+// OIHW (64,128,1,1) fp32 -> the chained-1x1 A-operand image [t2][t][g][lane][8]
+template <class E>
+__global__ void pack_chain1x1_16_kernel(const float* __restrict__ w, u16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 64 * 128 values
+  if (i >= 64 * 128) return;
+  const int j = i & 7, lane = (i >> 3) & 63, g = (i >> 9) & 1, t = (i >> 10) & 3, t2 = i >> 12;
+  const int co2 = t2 * 32 + (lane & 31);
+  const int c = t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+  out[i] = E::from_f32(w[co2 * 128 + c]);
+}
+
+int pack_chain1x1_16(const float* w, void* out, int dtype, hipStream_t stream) {
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(pack_chain1x1_16_kernel<EF16>, dim3(32), dim3(256), 0, stream, w, (u16*)out);
+  else
+    hipLaunchKernelGGL(pack_chain1x1_16_kernel<EBf16>, dim3(32), dim3(256), 0, stream, w, (u16*)out);
+  return check_launch("pack_chain1x1_16_kernel");
+}
+
+template <class E>
+static int launch_chain16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,
+                          const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+  Conv16Params p;
+  p.x = (const u16*)x; p.w = (const uint4*)w; p.y = (u16*)y; p.res = res ? (const u16*)res->data : nullptr;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = res ? res->ctotal * HW : 0;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = res ? res->coff * HW : 0;
+  p.w2 = (const uint4*)w_chain; p.y2 = (u16*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + 7) / 8;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, 128, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_mfma_bf16_kernel<fused 1x1>");
+}
+
+int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,
+                         const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+  CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: 16-bit kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
+  return d->dtype == CODON_F16 ? launch_chain16<EF16>(d, x, w, y, w_chain, out, res, stream)
+                               : launch_chain16<EBf16>(d, x, w, y, w_chain, out, res, stream);
+}
+
 template <class E, int KS, int CIN, int COUT, int COUTB = COUT>
 static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
                          hipStream_t stream) {
@@ -549,6 +686,7 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+  p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT, COUTB>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel");
 }

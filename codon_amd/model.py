@@ -207,7 +207,7 @@ class _CODONBase(nn.Module):
         def conv(xs, name, ys, k, **kw):   # one MFMA conv; 3x3 / 5x5 take the split-precision kernel when opted in
             ops.conv2d(xs, P(name), ys, k, f16x3=self._split(k), **kw)
 
-        chain = adt == torch.float32 and not self._split(5)
+        chain = not self._split(5)
 
         def conv5_1x1(xs, name5, name1, mid, ys, residual=None):
             """ys = conv1x1(relu(conv5x5(xs))) [+ residual]; mid = relu(conv5x5(xs)) is only materialised when the

@@ -52,6 +52,41 @@ def test_chain1x1_f32_vs_torch(shape):
     assert rel_rmse(o2.cpu(), o3.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_chain1x1_16bit(shape, dtype):
+    """16-bit tensors: same bar as the separate 16-bit launches (operands rounded to 16 bits, fp32 accumulate), and
+    the materialised intermediate is bit-identical to what the unfused conv stores."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x, w5, w1, r, _, _ = _case(shape)
+    q = lambda t: t.to(dtype).float()
+    mid_ref = q(F.relu(F.conv2d(q(x), q(w5), None, 1, 2)))
+    out_ref = F.conv2d(mid_ref, q(w1)) + q(r)
+    xd, rd = x.to(dev).to(dtype), r.to(dev).to(dtype)
+    wp = ops.packed_weight(w5.to(dev), L.PACK_FWD, dtype)
+    wc = ops.packed_weight(w1.to(dev), L.PACK_CHAIN1X1, dtype)
+    mid = torch.full((B, 128, H, W), float("nan"), device=dev, dtype=dtype)
+    out = torch.full((B, 128, H, W), float("nan"), device=dev, dtype=dtype)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(out, 0, 64), mid=Slice(mid), residual=Slice(rd))
+    assert torch.isnan(out[:, 64:]).all()
+    tol = 6e-3 if dtype == torch.bfloat16 else 8e-4
+    assert rel_rmse(out[:, :64].float().cpu(), out_ref) < tol
+    assert rel_rmse(mid.float().cpu(), mid_ref) < tol
+    m2 = torch.empty_like(mid)
+    ops.conv2d(Slice(xd), wp, Slice(m2), 5, relu=True)
+    assert torch.equal(m2, mid)
+    o3 = torch.empty((B, 64, H, W), device=dev, dtype=dtype)
+    ops.conv2d(Slice(m2), ops.packed_weight(w1.to(dev), L.PACK_FWD, dtype), Slice(o3), 1, residual=Slice(rd))
+    assert rel_rmse(out[:, :64].float().cpu(), o3.float().cpu()) < tol
+    # without the intermediate
+    o4 = torch.empty((B, 64, H, W), device=dev, dtype=dtype)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(o4), residual=Slice(rd))
+    assert torch.equal(o4, out[:, :64])
+
+
 def test_chain1x1_rejects_bad_arguments():
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
