@@ -36,6 +36,9 @@ int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, 
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
 int pack_chain1x1_f32(const float*, float*, hipStream_t);
 int pack_chain1x1_16(const float*, void*, int, hipStream_t);
+int pack_chain1x1_f32x3(const float*, void*, hipStream_t);
+int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const void*, const codon_tensor*,
+                            const codon_tensor*, hipStream_t);
 int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*, const void*, const codon_tensor*,
                          const codon_tensor*, hipStream_t);
 int conv_chain1x1_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, const codon_tensor*,
@@ -107,9 +110,13 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
                   CODON_ERR_UNSUPPORTED, "conv_pack_weight: f16x3 packing needs fp32, k in {3,5}, cin%%16==0, cout%%64==0");
     return pack_weight_f32x3(w_oihw, w_packed, cout, cin, ksize, (hipStream_t)stream);
   }
-  if (mode == CODON_PACK_CHAIN1X1) {
+  if (mode == CODON_PACK_CHAIN1X1 || mode == CODON_PACK_CHAIN1X1_F16X3) {
     CODON_REQUIRE(ksize == 1 && cin == 128 && cout == 64, CODON_ERR_UNSUPPORTED,
                   "conv_pack_weight: CHAIN1X1 packs the (64,128,1,1) weights only");
+    if (mode == CODON_PACK_CHAIN1X1_F16X3) {
+      CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: CHAIN1X1_F16X3 is for fp32 tensors");
+      return pack_chain1x1_f32x3(w_oihw, w_packed, (hipStream_t)stream);
+    }
     if (dtype == CODON_BF16 || dtype == CODON_F16) return pack_chain1x1_16(w_oihw, w_packed, dtype, (hipStream_t)stream);
     CODON_REQUIRE(dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_pack_weight: CHAIN1X1 dtype %d", dtype);
     return pack_chain1x1_f32(w_oihw, (float*)w_packed, (hipStream_t)stream);
@@ -176,8 +183,9 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
     CODON_REQUIRE(!(d->flags & CODON_CONV_F16X3), CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: F16X3 applies to fp32 tensors");
     return conv_chain1x1_fwd_16(d, x, w_packed, y, w_chain, out, residual, (hipStream_t)stream);
   }
-  CODON_REQUIRE(d->dtype == CODON_F32 && !(d->flags & CODON_CONV_F16X3), CODON_ERR_UNSUPPORTED,
-                "conv_chain1x1_fwd: dtype %d flags %d not supported", d->dtype, d->flags);
+  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: dtype %d", d->dtype);
+  if (d->flags & CODON_CONV_F16X3)
+    return conv_chain1x1_fwd_f32x3(d, (const float*)x, w_packed, (float*)y, w_chain, out, residual, (hipStream_t)stream);
   return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out,
                                residual, (hipStream_t)stream);
 }

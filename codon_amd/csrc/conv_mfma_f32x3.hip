@@ -44,6 +44,10 @@ struct ConvS3Params {
   long x_base, y_base, r_base;
   int tiles_x, tiles_y, nblk, ncob;
   int flags;
+  // FUSE only: chained 1x1 (128 -> 64) from the accumulators (conv_mfma_f32.hip), itself evaluated as 3 f16 MFMAs
+  const uint4* w2;  // [t2][t][g][part (hi, lo)][lane] x 16 B, W1 * 2^10 split; k order as in conv_mfma_bf16.hip
+  float* y2;
+  long y2_img, y2_base;
 };
 
 __device__ __forceinline__ u16 f2h_bits(float f) {
@@ -54,7 +58,7 @@ __device__ __forceinline__ float h2f_bits(u16 v) { return (float)*reinterpret_ca
 
 // COUTB couts and NW waves (NW*2 pixel rows) per workgroup:  <64, 4> = 8x32x64 tile, 68.6 KB LDS, 2 workgroups/CU;
 // <128, 8> = 16x32x128 tile, 126 KB LDS, one 8-wave workgroup per CU with 120 MFMAs per wave per barrier.
-template <int KS, int CIN, int COUTB, int NW>
+template <int KS, int CIN, int COUTB, int NW, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS3Params p) {
   constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
@@ -220,6 +224,84 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
 #undef STORE_W
 
   const int gx = tx0 + l31;
+  if constexpr (FUSE) {
+    // Chained 1x1: the fp32 tile (unscaled, ReLU'd) is split into fp16 hi + lo in registers -- registers 8g..8g+7
+    // of a D tile are the 8 k-values of the next MFMA's B operand -- and multiplied by the split, 2^10-scaled W1
+    // with the same three products as the main loop.
+    static_assert(!FUSE || COUTB == 128, "chained 1x1 is 128 -> 64");
+    const bool relu = p.flags & CODON_CONV_RELU;
+    constexpr float unscale = 1.f / (float)(1 << F3_WSCALE_LOG2);
+    float* __restrict__ yg = p.y ? p.y + (long)b * p.y_img + p.y_base : nullptr;
+    f16x8 bh[PSEG][CT][2], bl[PSEG][CT][2];
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) {
+      const int gy = ty0 + wave * PSEG + i;
+      const bool st = yg && gx < W && gy < H;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          u16 h8[8], l8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = acc[i][t][8 * g + j] * unscale;
+            if (relu) v = fmaxf(v, 0.f);
+            if (st) yg[(t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * half) * HW + (long)gy * W + gx] = v;
+            h8[j] = f2h_bits(v);
+            l8[j] = f2h_bits(v - h2f_bits(h8[j]));
+          }
+          bh[i][t][g] = *reinterpret_cast<const f16x8*>(h8);
+          bl[i][t][g] = *reinterpret_cast<const f16x8*>(l8);
+        }
+    }
+    const uint4* __restrict__ w2 = p.w2 + lane;
+    float* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
+    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+#pragma unroll 1
+    for (int t2 = 0; t2 < 2; ++t2) {
+      f32x16 d[PSEG];
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[i][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint4 hv = w2[(((t2 * CT + t) * 2 + g) * 2 + 0) * 64];
+          const uint4 lv = w2[(((t2 * CT + t) * 2 + g) * 2 + 1) * 64];
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(&hv), al = *reinterpret_cast<const f16x8*>(&lv);
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i) {
+            d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][t][g], d[i], 0, 0, 0);
+            d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][t][g], d[i], 0, 0, 0);
+            d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][t][g], d[i], 0, 0, 0);
+          }
+        }
+      if (gx < W) {
+#pragma unroll
+        for (int i = 0; i < PSEG; ++i) {
+          const int gy = ty0 + wave * PSEG + i;
+          if (gy < H) {
+            const long pix = (long)gy * W + gx;
+            if (rg) {
+              float rv[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] * unscale + rv[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] * unscale;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (gx < W) {
     float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
     const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
@@ -296,6 +378,49 @@ __global__ void pack_weight_f32x3_kernel(const float* __restrict__ w, u16* __res
   }
 }
 
+// OIHW (64,128,1,1) fp32 -> chained-1x1 A-operand image [t2][t][g][part][lane][8] fp16 (x 2^10, hi/lo split)
+__global__ void pack_chain1x1_f32x3_kernel(const float* __restrict__ w, u16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 64 * 128 values
+  if (i >= 64 * 128) return;
+  const int j = i & 7, lane = (i >> 3) & 63, g = (i >> 9) & 1, t = (i >> 10) & 3, t2 = i >> 12;
+  const int co2 = t2 * 32 + (lane & 31);
+  const int c = t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+  const float v = w[co2 * 128 + c] * (float)(1 << F3_WSCALE_LOG2);
+  const u16 hi = f2h_bits(v);
+  const u16 lo = f2h_bits(v - h2f_bits(hi));
+  const int base = (((t2 * 4 + t) * 2 + g) * 2) * 512 + lane * 8 + j;
+  out[base] = hi;
+  out[base + 512] = lo;
+}
+
+int pack_chain1x1_f32x3(const float* w, void* out, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_chain1x1_f32x3_kernel, dim3(32), dim3(256), 0, stream, w, (u16*)out);
+  return check_launch("pack_chain1x1_f32x3_kernel");
+}
+
+int conv_chain1x1_fwd_f32x3(const codon_conv_desc* d, const float* x, const void* w, float* y, const void* w_chain,
+                            const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+  CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: f16x3 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
+  constexpr int NW = 8;
+  ConvS3Params p;
+  p.x = x; p.w = (const uint4*)w; p.y = y; p.res = res ? (const float*)res->data : nullptr;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = res ? res->ctotal * HW : 0;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = res ? res->coff * HW : 0;
+  p.w2 = (const uint4*)w_chain; p.y2 = (float*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + 2 * NW - 1) / (2 * NW);
+  p.ncob = 1;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+  hipLaunchKernelGGL((conv_mfma_f32x3_kernel<5, 128, 128, NW, true>), dim3((unsigned)nblk), dim3(NW * 64), 0, stream, p);
+  return check_launch("conv_mfma_f32x3_kernel<fused 1x1>");
+}
+
 template <int KS, int CIN, int COUTB, int NW>
 static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, float* y, const float* res,
                      hipStream_t stream) {
@@ -312,6 +437,7 @@ static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, fl
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+  p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   hipLaunchKernelGGL((conv_mfma_f32x3_kernel<KS, CIN, COUTB, NW>), dim3((unsigned)nblk), dim3(NW * 64), 0, stream, p);
   return check_launch("conv_mfma_f32x3_kernel");
 }

@@ -50,7 +50,7 @@ def main(argv=None):
             io.write_gray(os.path.join(a.out, f), out_u8.cpu().numpy())
         line = f
         if a.label:
-            lab = torch.from_numpy(io.read_gray(os.path.join(a.label, f))).to(dev)
+            lab = torch.from_numpy(io.read_gray(os.path.join(a.label, f)).copy()).to(dev)
             rm = metrics.masked_rmse(lab, out_u8)
             ss = metrics.ssim(lab[:h, :w].float() / 255, out_u8.float() / 255)
             rm_sum += rm; ss_sum += ss

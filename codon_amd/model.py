@@ -207,17 +207,14 @@ class _CODONBase(nn.Module):
         def conv(xs, name, ys, k, **kw):   # one MFMA conv; 3x3 / 5x5 take the split-precision kernel when opted in
             ops.conv2d(xs, P(name), ys, k, f16x3=self._split(k), **kw)
 
-        chain = not self._split(5)
+        split5 = self._split(5)
+        chain_mode = L.PACK_CHAIN1X1_F16X3 if split5 else L.PACK_CHAIN1X1
 
         def conv5_1x1(xs, name5, name1, mid, ys, residual=None):
             """ys = conv1x1(relu(conv5x5(xs))) [+ residual]; mid = relu(conv5x5(xs)) is only materialised when the
             backward needs it (one launch: the 1x1 runs from the 5x5's accumulators)."""
-            if chain:
-                ops.conv_chain1x1(xs, P(name5), P(name1, L.PACK_CHAIN1X1), ys, mid=mid if keep else None,
-                                  residual=residual)
-            else:
-                conv(xs, name5, mid, 5, relu=True)
-                ops.conv2d(mid, P(name1), ys, 1, residual=residual)
+            ops.conv_chain1x1(xs, P(name5), P(name1, chain_mode), ys, mid=mid if keep else None, residual=residual,
+                              f16x3=split5)
 
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
 
@@ -342,7 +339,8 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
         P = self._packed
         S3, S5 = self._split(3), self._split(5)
-        t64, stage, r2, oc = new(64), new(128), new(128), new(128)
+        CM = L.PACK_CHAIN1X1_F16X3 if S5 else L.PACK_CHAIN1X1
+        t64, stage, oc = new(64), new(128), new(128)
 
         def stream(img, w_in, n_ci, c3x3, c5x5, first5, n3, nconf, out_slice):      # :53-74
             inputs = new(64)
@@ -353,9 +351,8 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
                 a, b = (c5x5, c3x3) if first5 else (c3x3, c5x5)
                 ops.conv2d(cur, P(a), Slice(stage, 0, 64), 5 if first5 else 3, relu=True, f16x3=S5 if first5 else S3)
                 ops.conv2d(cur, P(b), Slice(stage, 64, 64), 3 if first5 else 5, relu=True, f16x3=S3 if first5 else S5)
-                ops.conv2d(Slice(stage), P(n3), Slice(r2), 5, relu=True, f16x3=S5)
                 dst = out_slice if i == 4 else Slice(new(64))
-                ops.conv2d(Slice(r2), P(nconf), dst, 1, residual=Slice(inputs))     # confuse(...) + inputs
+                ops.conv_chain1x1(Slice(stage), P(n3), P(nconf, CM), dst, residual=Slice(inputs), f16x3=S5)  # confuse(relu(conv3)) + inputs
                 cur = dst
 
         stream(x, "input", "conv_input", "conv1", "conv2", False, "conv3", "confuse", Slice(oc, 0, 64))
@@ -366,8 +363,7 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         for _ in range(3):                                                          # :79-85
             ops.conv2d(Slice(f), P("conv8"), Slice(stage, 0, 64), 5, relu=True, f16x3=S5)
             ops.conv2d(Slice(f), P("conv9"), Slice(stage, 64, 64), 3, relu=True, f16x3=S3)
-            ops.conv2d(Slice(stage), P("conv10"), Slice(r2), 5, relu=True, f16x3=S5)
-            ops.conv2d(Slice(r2), P("confuse_fuse"), Slice(fA), 1, residual=Slice(fuse))
+            ops.conv_chain1x1(Slice(stage), P("conv10"), P("confuse_fuse", CM), Slice(fA), residual=Slice(fuse), f16x3=S5)
             f = fA
         ops.conv2d(Slice(f), P("conv11"), Slice(t64), 3, relu=True, f16x3=S3)                 # :87
         out = torch.empty_like(x)

@@ -49,7 +49,8 @@ enum {
                                   product; |activations| < 65504).  w_packed must come from CODON_PACK_FWD_F16X3. */
 };
 
-enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2, CODON_PACK_CHAIN1X1 = 3 };
+enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2, CODON_PACK_CHAIN1X1 = 3,
+       CODON_PACK_CHAIN1X1_F16X3 = 4 };
 
 /* One stride-1, "same"-padded, bias-free 2-D convolution (every nn.Conv2d of
  * CODON_X4/CODON_x4.py:24-47 has stride 1, padding k//2, bias=False). */
@@ -84,7 +85,8 @@ size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, 
  * mode CODON_PACK_FWD  : pack for y = conv(x, w)
  * mode CODON_PACK_DGRAD: pack the spatially flipped, in/out-transposed filter so that the SAME
  *                        forward kernel computes dL/dx = conv(dL/dy, w') (cin/cout swap roles).
- * mode CODON_PACK_CHAIN1X1: (64,128,1,1) only -- the register-chained 1x1 of codon_conv_chain1x1_fwd. */
+ * mode CODON_PACK_CHAIN1X1: (64,128,1,1) only -- the register-chained 1x1 of codon_conv_chain1x1_fwd;
+ *      CODON_PACK_CHAIN1X1_F16X3 the same for a CODON_CONV_F16X3 call (fp32 tensors). */
 int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, int32_t cin,
                            int32_t ksize, int32_t mode, int32_t dtype, codon_stream_t stream);
 
@@ -98,7 +100,7 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
  * registers and the 128-channel intermediate need not reach HBM: y may be NULL (inference); when given (training
  * saves it) it receives relu(conv5x5) exactly as codon_conv2d_fwd would write it.
  * d: the 5x5 conv (flags: CODON_CONV_RELU [| CODON_CONV_F16X3]; r_* ignored).  w_chain: the (64,128,1,1) weight
- * packed with mode CODON_PACK_CHAIN1X1 (same dtype; 64*128 elements).  out / residual: 64-channel slices of
+ * packed with mode CODON_PACK_CHAIN1X1 (CODON_PACK_CHAIN1X1_F16X3 under CODON_CONV_F16X3; same dtype; 64*128 elements).  out / residual: 64-channel slices of
  * d->dtype; residual may be NULL. */
 int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
                             const void* w_chain, const codon_tensor* out, const codon_tensor* residual,

@@ -87,6 +87,31 @@ def test_chain1x1_16bit(shape, dtype):
     assert torch.equal(o4, out[:, :64])
 
 
+@pytest.mark.parametrize("shape", SHAPES)
+def test_chain1x1_f16x3(shape):
+    """opt-in split-precision evaluation of fp32 tensors: both stages as 3 f16 MFMAs per product."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x, w5, w1, r, mid_ref, out_ref = _case(shape)
+    xd = x.to(dev)
+    wp = ops.packed_weight(w5.to(dev), L.PACK_FWD_F16X3)
+    wc = ops.packed_weight(w1.to(dev), L.PACK_CHAIN1X1_F16X3)
+    mid = torch.full((B, 128, H, W), float("nan"), device=dev)
+    out = torch.full((B, 128, H, W), float("nan"), device=dev)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(out, 64, 64), mid=Slice(mid), residual=Slice(r.to(dev)), f16x3=True)
+    assert torch.isnan(out[:, :64]).all()
+    assert rel_rmse(out[:, 64:].cpu(), out_ref + r) < 4e-6
+    assert rel_rmse(mid.cpu(), mid_ref) < 4e-6
+    m2 = torch.empty_like(mid)
+    ops.conv2d(Slice(xd), wp, Slice(m2), 5, relu=True, f16x3=True)
+    assert torch.equal(m2, mid)
+    o4 = torch.empty((B, 64, H, W), device=dev)
+    ops.conv_chain1x1(Slice(xd), wp, wc, Slice(o4), f16x3=True)
+    assert rel_rmse(o4.cpu(), out_ref) < 4e-6
+
+
 def test_chain1x1_rejects_bad_arguments():
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
