@@ -52,6 +52,42 @@ struct ConvCfg {
   static constexpr int NCHUNK = CIN / CK;
 };
 
+// VALU BUDGET.  Measured on gfx950 (tools/exp_timing.py): a VALU instruction of ANY wave of the SIMD
+// takes 4 cycles out of the matrix pipe (2 dummy v_add per MFMA: 55.8 -> 62.5 ms on conv5x5-128), while SALU / LDS /
+// VMEM issue is free.  Once the MFMA stream is dense, every address computation, select and convert is therefore paid
+// for in MFMA time -- and a wave in its (VALU-only) prologue or epilogue gets one issue slot per 64-cycle MFMA of its
+// co-resident waves.  So every global access below is a BUFFER instruction: a wave-uniform SGPR offset carries the
+// channel / chunk / stage term, one hoisted 32-bit VGPR offset per element carries the lane term, out-of-image and
+// padding elements use an out-of-range offset (the load returns 0, the store is dropped), and no 64-bit address
+// arithmetic, exec-mask branch or zero-fill select is left in the per-stage or per-element code.
+constexpr unsigned BUF_OOB = 0xFFFFFFF0u;     // >= num_records of every descriptor below (checked by the launcher)
+constexpr int BUF_FLAGS = 0x00020000;         // raw buffer, 32-bit data format
+
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+}
+__device__ __forceinline__ void buf_st(float v, __amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, vo, so, 0);
+}
+
+// ReLU in ONE VALU op: fmaxf() compiles to a canonicalising v_max(v, v) plus the v_max(0, v) on MFMA results
+__device__ __forceinline__ float relu1(float v) {
+  float o;
+  asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(v));
+  return o;
+}
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+// residual modes of the epilogue (compile-time variants: one VALU op per element each)
+enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
+
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams p) {
   constexpr int PAD = KS / 2;
@@ -59,18 +95,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = ConvCfg<KS, CIN>::CK;
   constexpr int NCHUNK = CIN / CK;
-  constexpr int XS = CK * XR * XQ;    // floats per input buffer
+  constexpr int XS = CK * XR * XQ;    // floats per input tile
   constexpr int WS = CK * KS * COUT;  // floats per weight stage
   constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * KS;
   constexpr int XE = (XS + 255) / 256;  // x elements per thread per chunk
   constexpr int W4 = WS / 4;            // float4 per weight stage
   constexpr int WE = (W4 + 255) / 256;  // float4 per thread per stage
+  constexpr int XSP = XE * 256, WSP = WE * 256 * 4;   // LDS buffers padded to whole rounds: no store predicates
   static_assert(WS % 4 == 0, "weight stage must be whole float4s");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * XS + 2 * WS];
+  __shared__ __attribute__((aligned(16))) float lds[2 * XSP + 2 * WSP];
   float* const xs0 = lds;
-  float* const ws0 = lds + 2 * XS;
+  float* const ws0 = lds + 2 * XSP;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,26 +122,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   const int b = bid / p.tiles_y;
   const int tx0 = tx * TW, ty0 = ty * TH;
   const int H = p.H, W = p.W;
-  const long HW = (long)H * W;
+  const unsigned HW4 = 4u * (unsigned)H * (unsigned)W;   // bytes per channel plane (launcher: 128 planes < 4 GiB)
 
-  const float* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
-  const float4* __restrict__ wg = reinterpret_cast<const float4*>(p.w);
+  // wave-uniform buffer descriptors: this image's input slice, the packed weights
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)CIN * HW4), BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 4), BUF_FLAGS);
 
-  // per-thread gather plan for the input halo tile (same for every chunk)
-  int xoff[XE];
-  unsigned xmask = 0;
+  // per-thread gather plan for the input halo tile (same for every chunk): element e = tid + 256 k = (c, r, q),
+  // walked incrementally (one division for k = 0, carries afterwards); out-of-image / padding -> BUF_OOB
+  unsigned xoff[XE];
+  {
+    constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
+    int c = tid / (XR * XQ);
+    int rem = tid - c * (XR * XQ);
+    int r = rem / XQ, q = rem - r * XQ;
 #pragma unroll
-  for (int k = 0; k < XE; ++k) {
-    const int e = tid + k * 256;
-    const int c = e / (XR * XQ);
-    const int rem = e - c * (XR * XQ);
-    const int r = rem / XQ;
-    const int q = rem - r * XQ;
-    const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
-    const bool ok = (e < XS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    xoff[k] = ok ? (int)(c * HW + (long)gy * W + gx) : 0;
-    xmask |= ok ? (1u << k) : 0u;
+    for (int k = 0; k < XE; ++k) {
+      const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+      const bool ok = c < CK && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xoff[k] = ok ? (unsigned)c * HW4 + 4u * (unsigned)(gy * W + gx) : BUF_OOB;
+      q += DQ; r += DR; c += DC;
+      if (q >= XQ) { q -= XQ; r += 1; }
+      if (r >= XR) { r -= XR; c += 1; }
+    }
   }
+  // weight stage: float4 element tid + 256 k of the stage; the padding round is out of range
+  const unsigned wvo = (unsigned)tid * 16u;
+  const unsigned wvo_last = (W4 % 256 == 0 || tid + (WE - 1) * 256 < W4) ? wvo : BUF_OOB;
 
   float xr[XE];
   float4 wr[WE];
@@ -112,30 +158,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 // staging steps as macros (not lambdas): keeps xr/wr in registers (no alloca left for scratch)
 #define LOAD_X(chunk_)                                                             \
   {                                                                                \
-    const float* src_ = xg + (long)(chunk_) * CK * HW;                             \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k)                                 \
-        xr[k] = src_[xoff[k]];  /* unconditional (xoff = 0, in bounds, when masked); mask applied at STORE_X */ \
+    const unsigned so_ = (unsigned)(chunk_) * (unsigned)CK * HW4;                  \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xrsrc, xoff[k], so_); \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \
-    float* dst_ = xs0 + (buf_) * XS;                                               \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) {                               \
-      const int e_ = tid + k * 256;                                                \
-      if (XS % 256 == 0 || e_ < XS) dst_[e_] = ((xmask >> k) & 1u) ? xr[k] : 0.f;  \
-    }                                                                              \
+    float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k) dst_[k * 256] = xr[k];          \
   }
 #define LOAD_W(stage_)                                                             \
   {                                                                                \
-    const float4* src_ = wg + (long)(stage_) * W4;                                 \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                 \
-        wr[k] = (W4 % 256 == 0 || tid + k * 256 < W4) ? src_[tid + k * 256]        \
-                                                      : make_float4(0, 0, 0, 0);   \
+    const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 4);                  \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) {                               \
+      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * 4096u, 0); \
+      wr[k] = *reinterpret_cast<const float4*>(&v_);                               \
+    }                                                                              \
   }
 #define STORE_W(buf_)                                                              \
   {                                                                                \
-    float4* dst_ = reinterpret_cast<float4*>(ws0 + (buf_) * WS);                   \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                 \
-        if (W4 % 256 == 0 || tid + k * 256 < W4) dst_[tid + k * 256] = wr[k];      \
+    float4* dst_ = reinterpret_cast<float4*>(ws0 + (buf_) * WSP) + tid;            \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) dst_[k * 256] = wr[k];          \
   }
 
   f32x16 acc[PSEG][CT];
@@ -162,24 +204,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
     if (has_next) LOAD_W(s + 1);
     if (next_chunk) LOAD_X(chunk + 1);
 
-    const float* xb = xs0 + (chunk & 1) * XS + (half * XR + wave * PSEG + dy) * XQ + l31;
-    const float* wb = ws0 + (s & 1) * WS + half * (KS * COUT) + l31;
+    // volatile: keeps every operand fetch a ds_read_b32 with a 16-bit immediate offset off ONE base register; left
+    // alone, hipcc pairs them into ds_read2_b32 (8-bit offsets) and pays a v_add_u32 re-base per pair -- VALU ops
+    // that cost matrix-pipe time, where the extra LDS instructions are free.
+    typedef const volatile __attribute__((address_space(3))) float* lds_cvp;
+    const lds_cvp xb = (lds_cvp)(xs0 + (chunk & 1) * XSP + (half * XR + wave * PSEG + dy) * XQ + l31);
+    const lds_cvp wb = (lds_cvp)(ws0 + (s & 1) * WSP + half * (KS * COUT) + l31);
+    // operand fetch for group g = (dx, cp) is issued one group ahead of its MFMAs (two register sets)
+    constexpr int NG = KS * (CK / 2);
+    float a[2][CT], bv[2][PSEG];
+#define FETCH(g_)                                                                                        \
+  {                                                                                                      \
+    constexpr int dx_ = (g_) / (CK / 2), cp_ = (g_) % (CK / 2);                                          \
+    _Pragma("unroll") for (int t = 0; t < CT; ++t) a[(g_) & 1][t] = wb[((2 * cp_) * KS + dx_) * COUT + t * 32]; \
+    _Pragma("unroll") for (int i = 0; i < PSEG; ++i) bv[(g_) & 1][i] = xb[(2 * cp_) * (XR * XQ) + i * XQ + dx_]; \
+  }
+    FETCH(0)
+    static_for<NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 1 < NG) FETCH(g + 1)
+      __builtin_amdgcn_sched_barrier(0);   // keep the fetch of g+1 ahead of the MFMAs of g (else it is sunk to its use)
 #pragma unroll
-    for (int dx = 0; dx < KS; ++dx) {
+      for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-      for (int cp = 0; cp < CK / 2; ++cp) {
-        float a[CT], bv[PSEG];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) a[t] = wb[((2 * cp) * KS + dx) * COUT + t * 32];
-#pragma unroll
-        for (int i = 0; i < PSEG; ++i) bv[i] = xb[(2 * cp) * (XR * XQ) + i * XQ + dx];
-#pragma unroll
-        for (int i = 0; i < PSEG; ++i)
-#pragma unroll
-          for (int t = 0; t < CT; ++t)
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv[i], acc[i][t], 0, 0, 0);
-      }
-    }
+        for (int t = 0; t < CT; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][t], bv[g & 1][i], acc[i][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#undef FETCH
 
     if (has_next) STORE_W((s + 1) & 1);
     if (next_chunk) STORE_X((chunk + 1) & 1);
@@ -191,10 +243,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 #undef LOAD_W
 #undef STORE_W
 
-  // epilogue: ReLU / residual / accumulate, coalesced NCHW stores.  Flag tests hoisted into four wave-uniform
-  // variants: inside a variant the residual / accumulate loads of a tile are unconditional and issued back to
-  // back (a per-element `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
+  // epilogue.  Lane term of every output address: pixel (row of this wave's segment i, column l31) of cout plane
+  // 4*half; the cout term (t, r) is wave-uniform and goes into the SGPR offset.  Off-image pixels -> BUF_OOB.
   const int gx = tx0 + l31;
+  unsigned vo[PSEG];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i) {
+    const int gy = ty0 + wave * PSEG + i;
+    vo[i] = (gx < W && gy < H) ? (unsigned)(4 * half) * HW4 + 4u * (unsigned)(gy * W + gx) : BUF_OOB;
+  }
+  const bool relu = p.flags & CODON_CONV_RELU;
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)(FUSE ? 64 : COUT) * HW4), BUF_FLAGS);
+
   if constexpr (FUSE) {
     // Chained 1x1: the D layout of the 32x32 MFMA (lane = pixel l&31, register r = channel (r&3)+8(r>>2)+4(l>>5))
     // IS a B operand of the next MFMA for the channel pair {c, c+4}: lanes 0-31 carry k = 0, lanes 32-63 k = 1 of
@@ -202,30 +263,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
     // registers -- 64 MFMAs per 32 output channels and pixel row, no LDS round trip, and the 128-channel
     // intermediate never has to reach HBM (p.y == nullptr).  W1 is pre-permuted to that k order by the packer.
     static_assert(!FUSE || COUT == 128, "chained 1x1 is 128 -> 64");
-    const bool relu = p.flags & CODON_CONV_RELU;
+    if (relu) {
 #pragma unroll
-    for (int i = 0; i < PSEG; ++i)
+      for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][t][r] = relu ? fmaxf(acc[i][t][r], 0.f) : acc[i][t][r];
-    if (p.y && gx < W) {
-      float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
-#pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
-#pragma unroll
-          for (int t = 0; t < CT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + (long)gy * W + gx] = acc[i][t][r];
-        }
-      }
+          for (int r = 0; r < 16; ++r) acc[i][t][r] = relu1(acc[i][t][r]);
     }
-    const float4* __restrict__ w2 = reinterpret_cast<const float4*>(p.w2) + lane * 4;
-    float* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
-    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    if (p.y) {
+      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW4), BUF_FLAGS);
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            buf_st(acc[i][t][r], yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+    }
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(64u * HW4), BUF_FLAGS);
+    const unsigned w2vo = (unsigned)lane * 64u;
 #pragma unroll 1
     for (int t2 = 0; t2 < 2; ++t2) {
       f32x16 d[PSEG];
@@ -237,7 +297,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
       for (int t = 0; t < CT; ++t) {
         float4 a4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a4[q] = w2[((t2 * CT + t) * 64) * 4 + q];
+        for (int q = 0; q < 4; ++q) {
+          const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2vo, (unsigned)((t2 * CT + t) * 4096 + q * 16), 0);
+          a4[q] = *reinterpret_cast<const float4*>(&v_);
+        }
         const float* a = reinterpret_cast<const float*>(a4);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -245,74 +308,78 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
           for (int i = 0; i < PSEG; ++i)
             d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[i][t][r], d[i], 0, 0, 0);
       }
-      if (gx < W) {
+      const unsigned so2 = (unsigned)(t2 * 32) * HW4;
+      if (p.res) {
 #pragma unroll
         for (int i = 0; i < PSEG; ++i) {
-          const int gy = ty0 + wave * PSEG + i;
-          if (gy < H) {
-            const long pix = (long)gy * W + gx;
-            if (rg) {
-              float rv[16];
+          float rv[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] + rv[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r];
-            }
-          }
+          for (int r = 0; r < 16; ++r) buf_st(d[i][r] + rv[r], y2rsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) buf_st(d[i][r], y2rsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
       }
     }
     return;
   }
-  if (gx < W) {
-    float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
-    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
-    const bool relu = p.flags & CODON_CONV_RELU;
-    const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
-    const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
-    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
-    auto epi = [&](auto has_r, auto has_acc) {
+
+  // ReLU / residual / accumulate as compile-time variants selected by wave-uniform branches: inside a variant every
+  // element costs its store plus at most two VALU ops, and the 16 loads of a tile are issued back to back.
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW4), BUF_FLAGS);
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    constexpr int RES = decltype(res_c)::value;
+    constexpr bool ACC = decltype(acc_c)::value;
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
-          const long pix = (long)gy * W + gx;
+    for (int i = 0; i < PSEG; ++i) {
 #pragma unroll
-          for (int t = 0; t < CT; ++t) {
-            float rv[16], av[16];
-            if constexpr (decltype(has_r)::value) {
+      for (int t = 0; t < CT; ++t) {
+        float rv[16], av[16];
+        if constexpr (RES != RES_NONE) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
-            }
-            if constexpr (decltype(has_acc)::value) {
+          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+        }
+        if constexpr (ACC) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) av[r] = yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
-            }
+          for (int r = 0; r < 16; ++r) av[r] = buf_ld(yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float v = acc[i][t][r];
-              if (relu) v = fmaxf(v, 0.f);
-              if constexpr (decltype(has_r)::value) {
-                if (addr) v += rv[r];
-                if (mask) v = rv[r] > 0.f ? v : 0.f;
-              }
-              if constexpr (decltype(has_acc)::value) v += av[r];
-              yg[co * HW + pix] = v;
-            }
-          }
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][t][r];
+          if constexpr (RELU) v = relu1(v);
+          if constexpr (RES == RES_ADD) v += rv[r];
+          if constexpr (RES == RES_MASK) v = rv[r] > 0.f ? v : 0.f;
+          if constexpr (ACC) v += av[r];
+          buf_st(v, yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
         }
       }
-    };
-    const bool has_r = addr || mask;
-    if (has_r && accum) epi(std::true_type{}, std::true_type{});
-    else if (has_r) epi(std::true_type{}, std::false_type{});
-    else if (accum) epi(std::false_type{}, std::true_type{});
-    else epi(std::false_type{}, std::false_type{});
-  }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using R0 = std::integral_constant<int, RES_NONE>;
+  using R1 = std::integral_constant<int, RES_ADD>;
+  using R2 = std::integral_constant<int, RES_MASK>;
+  const int res_mode = !p.res ? RES_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RES_MASK
+                                         : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RES_ADD : RES_NONE;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  auto by_acc = [&](auto relu_c, auto res_c) {
+    if (accum) epi(relu_c, res_c, T{});
+    else epi(relu_c, res_c, F{});
+  };
+  auto by_res = [&](auto relu_c) {
+    if (res_mode == RES_NONE) by_acc(relu_c, R0{});
+    else if (res_mode == RES_ADD) by_acc(relu_c, R1{});
+    else by_acc(relu_c, R2{});
+  };
+  if (relu) by_res(T{});
+  else by_res(F{});
 }
 
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
@@ -365,6 +432,8 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  CODON_REQUIRE(HW * 4 * 128 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
@@ -391,6 +460,8 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
+  CODON_REQUIRE(HW * 4 * 128 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
