@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "codon_hip.h"
 
@@ -29,6 +30,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + k;
 }
+
+// Debug builds only (make EXTRA=-DCODON_TIMING, tools/exp_timing.py): per-workgroup phase timestamps (100 MHz
+// wall clock) written to the buffer whose address is in the environment variable CODON_DBG_PTR at launch time.
+#ifdef CODON_TIMING
+#define CODON_TSTAMP(dbg_, k_) \
+  if (threadIdx.x == 0 && (dbg_)) (dbg_)[(long)blockIdx.x * 8 + (k_)] = (long long)wall_clock64();
+inline long long* codon_dbg_ptr() {
+  const char* e = getenv("CODON_DBG_PTR");
+  return e ? (long long*)strtoull(e, nullptr, 16) : nullptr;
+}
+#else
+#define CODON_TSTAMP(dbg_, k_)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -59,6 +59,9 @@ struct Conv16Params {
   long x_base, y_base, r_base;
   int tiles_x, tiles_y, nblk;
   int flags;
+#ifdef CODON_TIMING
+  long long* dbg;
+#endif
   // FUSE only: chained 1x1 (128 -> 64) from the accumulators, see conv_mfma_f32.hip
   const uint4* w2;  // [t2][t][g][lane] x 16 B: W1[t2*32 + (lane&31)][t*32 + 16g + (j&3) + 8(j>>2) + 4(lane>>5)], j = 0..7
   u16* y2;
@@ -72,122 +75,139 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
   return *reinterpret_cast<u16*>(&b);
 }
 
-// COUTB = couts per workgroup (64 or COUT): with COUTB = 64 < COUT the grid also walks cout blocks -- half the
-// accumulators and LDS per workgroup (3 workgroups per CU instead of 2), at the price of staging x twice.
-template <class E, int KS, int CIN, int COUT, int COUTB, bool FUSE = false>
+// VALU BUDGET (see conv_mfma_f32.hip): a VALU instruction costs 4 matrix-pipe cycles, i.e. 1/8 of a 32-cycle
+// 16-bit MFMA, so this kernel keeps VALU out of the steady state altogether:
+//   * every global access is a buffer instruction (SGPR channel / chunk / stage offset + one hoisted 32-bit VGPR
+//     offset per element; out-of-image and padding elements are out of range: loads return 0, stores are dropped);
+//   * the stage loop is unrolled over a chunk PAIR x KS filter rows, so both LDS double-buffer parities are compile
+//     time and every ds_read_b128 / ds_write_b16 / ds_write_b128 is `base VGPR + immediate`;
+//   * operand fetches are volatile LDS reads (never re-paired / re-based by the compiler) issued one filter tap
+//     ahead of their MFMAs, held there by sched_barrier;
+//   * the two channels of a staged word are written as two ds_write_b16 (no v_perm pack, no zero-fill select).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF16_OOB = 0xFFFFFFF0u;
+constexpr int BUF16_FLAGS = 0x00020000;
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for16(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for16<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+__device__ __forceinline__ float relu1_16(float v) {   // one v_max (fmaxf adds a canonicalising v_max(v, v))
+  float o;
+  asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(v));
+  return o;
+}
+
+enum { RES16_NONE = 0, RES16_ADD = 1, RES16_MASK = 2 };
+
+template <class E, int KS, int CIN, int COUT, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
+  typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
+  typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
   constexpr int PAD = KS / 2;
   constexpr int PSEG = 2;
   constexpr int TW = 32, TH = 4 * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = 16, NCB = CK / 8;
   constexpr int NCHUNK = CIN / CK;
-  constexpr int XS = NCB * XR * XQ;   // 16-byte elements per input buffer
-  constexpr int WSG = KS * NCB * COUT;  // 16-byte elements per weight stage in the packed (global) image
-  constexpr int WS = KS * NCB * COUTB;  // ... of which this workgroup stages its COUTB couts
-  constexpr int CT = COUTB / 32;
-  constexpr int NCOB = COUT / COUTB;
+  constexpr int XS = NCB * XR * XQ;       // 16-byte elements per input tile
+  constexpr int WS = KS * NCB * COUT;     // 16-byte elements per weight stage
+  constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * KS;
-  constexpr int XW = (CK / 2) * XR * XQ;  // 32-bit words (channel pairs) per input tile
-  constexpr int XE = (XW + 255) / 256;
+  constexpr int XE = (XS + 255) / 256;    // 16-byte elements (8 channels of a pixel) per thread per chunk
   constexpr int WE = (WS + 255) / 256;
+  constexpr int XSP = XE * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
+  static_assert(NCHUNK % 2 == 0, "the stage loop is unrolled over chunk pairs");
+  static_assert(2 * XSP * 16 < 65536 && 2 * WSP * 16 < 65536, "LDS immediates are 16 bits per region");
 
-  __shared__ uint4 lds[2 * XS + 2 * WS];
+  __shared__ uint4 lds[2 * XSP + 2 * WSP];
   uint4* const xs0 = lds;
-  uint4* const ws0 = lds + 2 * XS;
+  uint4* const ws0 = lds + 2 * XSP;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
 
+  CODON_TSTAMP(p.dbg, 0)
   unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
-  const int cob = bid % NCOB;
-  bid /= NCOB;
   const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int b = bid / p.tiles_y;
   const int tx0 = tx * TW, ty0 = ty * TH;
   const int H = p.H, W = p.W;
-  const long HW = (long)H * W;
+  const unsigned HW2 = 2u * (unsigned)H * (unsigned)W;   // bytes per channel plane
 
-  const u16* __restrict__ xg = p.x + (long)b * p.x_img + p.x_base;
-  const uint4* __restrict__ wg = p.w;
-  // buffer descriptors (wave-uniform): this image's CIN-channel slice, and the packed weight image
-  const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (int)((unsigned)CIN * 2u * (unsigned)HW), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)CIN * HW2), BUF16_FLAGS);
   const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WSG * 16), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 16), BUF16_FLAGS);
 
-  // gather plan: word e = (channel pair cp, row r, col q), q fastest (coalesced along W)
-  unsigned xoff[XE];   // unsigned element offsets: zero-extended, so loads can use SGPR base + 32-bit VGPR offset
-  int xdst[XE];
-  unsigned xmask = 0;
+  // gather plan: 16-byte element e = tid + 256 k = (channel block cb, row r, col q) of the channel-blocked LDS image
+  // xs[cb][r][q] -- the LDS index IS e, so a staging round is one conflict-free ds_write_b128 per thread at
+  // `tid*16 + immediate` (the 4-byte-per-thread version wrote 16-byte-strided words: 8-way bank conflicts on the
+  // resource this kernel is shortest of).  Its 8 channels come from 8 plane loads (wave = 64 consecutive pixels of
+  // one plane per instruction) whose plane term is an SGPR.  xoff: byte offset of (plane cb*8, pixel) or out of range.
+  unsigned xoff[XE];
+  {
+    constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
+    int cb = tid / (XR * XQ);
+    int rem = tid - cb * (XR * XQ);
+    int r = rem / XQ, q = rem - r * XQ;
 #pragma unroll
-  for (int k = 0; k < XE; ++k) {
-    const int e = tid + k * 256;
-    const int cp = e / (XR * XQ);
-    const int rem = e - cp * (XR * XQ);
-    const int r = rem / XQ, q = rem - r * XQ;
-    const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
-    const bool ok = (e < XW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    xoff[k] = ok ? 2u * (unsigned)((2 * cp) * HW + (long)gy * W + gx) : 0u;   // BYTE offset inside the image slice
-    xmask |= ok ? (1u << k) : 0u;
-    // destination 32-bit word index inside the blocked image: element ((cp/4)*XR + r)*XQ + q, word cp%4
-    xdst[k] = (((cp >> 2) * XR + r) * XQ + q) * 4 + (cp & 3);
+    for (int k = 0; k < XE; ++k) {
+      const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+      const bool ok = cb < NCB && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xoff[k] = ok ? (unsigned)(8 * cb) * HW2 + 2u * (unsigned)(gy * W + gx) : BUF16_OOB;
+      q += DQ; r += DR; cb += DC;
+      if (q >= XQ) { q -= XQ; r += 1; }
+      if (r >= XR) { r -= XR; cb += 1; }
+    }
   }
+  const lds_w128 xwr = (lds_w128)(xs0 + tid);
+  const unsigned wvo = (unsigned)tid * 16u;
+  const unsigned wvo_last = (WS % 256 == 0 || tid + (WE - 1) * 256 < WS) ? wvo : BUF16_OOB;
+  const lds_w128 ww = (lds_w128)(ws0 + tid);
+  const lds_rd xrd = (lds_rd)(xs0 + (half * XR + wave * PSEG) * XQ + l31);
+  const lds_rd wrd = (lds_rd)(ws0 + half * COUT + l31);
 
-  const bool interior = ty0 >= PAD && ty0 + TH + PAD <= H && tx0 >= PAD && tx0 + TW + PAD <= W;   // block-uniform
-  // The two channels of a word stay in two registers until STORE_X writes them as two ds_write_b16: packing
-  // `lo | hi << 16` (or a 2-vector) at load time made hipcc wait for every prefetch load right after issuing it.
-  u16 xlo[XE], xhi[XE];
-  uint4 wr[WE];
+  // the next chunk's halo tile is fetched in two halves, during the last two filter rows of the current chunk
+  constexpr int XE1 = (KS >= 3) ? XE / 2 : 0, XEH = XE - XE1;
+  u16 xv[XEH][8];
+  u32x4 wr[WE];
 
-#define LOAD_X(chunk_)                                                                  \
+#define LOAD_X(chunk_, k0_, k1_)                                                        \
   {                                                                                     \
-    /* buffer loads: SGPR descriptor + SGPR chunk offset + hoisted 32-bit VGPR offset -> no per-load address */ \
-    /* VALU (the SIMD's issue slots are what this kernel runs out of).  Unconditional (xoff = 0 when masked). */ \
-    const unsigned so_ = (unsigned)(chunk_) * (unsigned)(CK * 2) * (unsigned)HW;        \
-    const unsigned so_hi_ = so_ + 2u * (unsigned)HW;                                    \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                    \
-      xlo[k] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, xoff[k], so_, 0);            \
-      xhi[k] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, xoff[k], so_hi_, 0);         \
-    }                                                                                   \
+    const unsigned so_ = (unsigned)(chunk_) * (unsigned)CK * HW2;                       \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k)                               \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                     \
+        xv[k - (k0_)][j] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, xoff[k], so_ + (unsigned)j * HW2, 0); \
   }
-#define STORE_X(buf_)                                                                   \
+#define STORE_X(buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */            \
   {                                                                                     \
-    u16* dst_ = reinterpret_cast<u16*>(xs0 + (buf_) * XS);                              \
-    if (interior) { /* tile + halo fully inside the image (87 % of the tiles at 480x640): no zero-fill selects */ \
-      _Pragma("unroll") for (int k = 0; k < XE; ++k)                                    \
-          if (XW % 256 == 0 || tid + k * 256 < XW) {                                    \
-            dst_[2 * xdst[k]] = xlo[k];                                                 \
-            dst_[2 * xdst[k] + 1] = xhi[k];                                             \
-          }                                                                             \
-    } else {                                                                            \
-      _Pragma("unroll") for (int k = 0; k < XE; ++k)                                    \
-          if (XW % 256 == 0 || tid + k * 256 < XW) {                                    \
-            const bool m_ = (xmask >> k) & 1u;                                          \
-            dst_[2 * xdst[k]] = m_ ? xlo[k] : (u16)0;                                   \
-            dst_[2 * xdst[k] + 1] = m_ ? xhi[k] : (u16)0;                               \
-          }                                                                             \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
+      u32x4 v_;                                                                         \
+      _Pragma("unroll") for (int w = 0; w < 4; ++w)                                     \
+        v_[w] = (unsigned)xv[k - (k0_)][2 * w] | ((unsigned)xv[k - (k0_)][2 * w + 1] << 16); \
+      xwr[(buf_) * XSP + k * 256] = v_;                                                 \
     }                                                                                   \
   }
 #define LOAD_W(stage_)                                                                  \
   {                                                                                     \
-    const unsigned wso_ = (unsigned)(stage_) * (unsigned)(WSG * 16) + (unsigned)(cob * COUTB * 16); \
+    const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
-      const int e_ = tid + k * 256;   /* element e_ = (row = dx*NCB+cb, o): global element row*COUT + o */ \
-      const unsigned vo_ = (WS % 256 == 0 || e_ < WS) ? (unsigned)((e_ / COUTB) * COUT + (e_ % COUTB)) * 16u : 0u; \
-      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo_, wso_, 0);        \
-      wr[k] = *reinterpret_cast<const uint4*>(&v_);                                     \
+      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * 4096u, 0); \
+      wr[k] = *reinterpret_cast<const u32x4*>(&v_);                                     \
     }                                                                                   \
   }
 #define STORE_W(buf_)                                                                   \
   {                                                                                     \
-    uint4* dst_ = ws0 + (buf_) * WS;                                                    \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
-        if (WS % 256 == 0 || tid + k * 256 < WS) dst_[tid + k * 256] = wr[k];           \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * 256] = wr[k];  \
   }
 
   f32x16 acc[PSEG][CT];
@@ -198,63 +218,109 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-  LOAD_X(0);
+  if constexpr (XE1 > 0) {
+    LOAD_X(0, 0, XE1);
+    STORE_X(0, 0, XE1);
+  }
+  LOAD_X(0, XE1, XE);
   LOAD_W(0);
-  STORE_X(0);
+  STORE_X(0, XE1, XE);
   STORE_W(0);
+  CODON_TSTAMP(p.dbg, 1)
   __syncthreads();
+  CODON_TSTAMP(p.dbg, 2)
 
+  // stage (chunk, dy): weights of filter row dy for 16 channels in ws[(chunk*KS + dy) & 1], the chunk's halo tile
+  // in xs[chunk & 1].  Unrolled over (chunk parity, dy): KS odd, so the stage parity is (par + dy) & 1.
 #pragma unroll 1
-  for (int s = 0; s < NST; ++s) {
-    const int chunk = s / KS;
-    const int dy = s - chunk * KS;
-    const bool has_next = (s + 1 < NST);
-    const bool next_chunk = has_next && (dy == KS - 1);
-    if (has_next) LOAD_W(s + 1);
-    if (next_chunk) LOAD_X(chunk + 1);
+  for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
+    static_for16<2 * KS>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int par = u / KS, dy = u % KS;
+      constexpr int sbuf = (par + dy) & 1;
+      const int chunk = c2 + par;
+      const int s = chunk * KS + dy;
+      constexpr bool tail = (par == 1 && dy == KS - 1);           // last stage of the pair
+      const bool has_next = !tail || (c2 + 2 < NCHUNK);
+      if (has_next) {
+        LOAD_W(s + 1);
+        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, XE1, XE);
+      }
+      if constexpr (XE1 > 0 && dy == KS - 2) {
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, 0, XE1);
+      }
 
-    const uint4* xb = xs0 + (chunk & 1) * XS + (half * XR + wave * PSEG + dy) * XQ + l31;
-    const uint4* wb = ws0 + (s & 1) * WS + half * COUTB + l31;
-#pragma unroll
-    for (int dx = 0; dx < KS; ++dx) {
-      vec8 a[CT], bv[PSEG];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        const uint4 v = wb[dx * NCB * COUTB + t * 32];
-        a[t] = *reinterpret_cast<const vec8*>(&v);
-      }
-#pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const uint4 v = xb[i * XQ + dx];
-        bv[i] = *reinterpret_cast<const vec8*>(&v);
-      }
-#pragma unroll
-      for (int i = 0; i < PSEG; ++i)
+      // Operand fetch one filter tap ahead of its MFMAs, in two register sets.  PIN: sched_barrier holds that order
+      // (the scheduler otherwise sinks every fetch down to its use) -- measured on one box (A/B, same call): pinned
+      // wins on the 8-MFMA taps of conv5x5-128 (6.59 vs 6.75 ms), unpinned on the 3x3 convs (1.13 vs 1.21 ms).
+      constexpr bool PIN = (KS == 5 && CT == 4);
+      vec8 a[2][CT], bv[2][PSEG];
+#define FETCH_A(dx_, t_)                                                                                  \
+  {                                                                                                       \
+    const u32x4 v_ = wrd[sbuf * WSP + (dx_) * NCB * COUT + (t_) * 32];                                    \
+    a[(dx_) & 1][t_] = *reinterpret_cast<const vec8*>(&v_);                                               \
+  }
+#define FETCH_B(dx_)                                                                                      \
+  {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < PSEG; ++i) {                                                    \
+      const u32x4 v_ = xrd[par * XSP + (dy + i) * XQ + (dx_)];                                            \
+      bv[(dx_) & 1][i] = *reinterpret_cast<const vec8*>(&v_);                                             \
+    }                                                                                                     \
+  }
+      static_for16<CT>([&](auto tc) { FETCH_A(0, decltype(tc)::value) });
+      FETCH_B(0)
+      static_for16<KS>([&](auto dc) {
+        constexpr int dx = decltype(dc)::value;
+        if constexpr (dx + 1 < KS) {
+          FETCH_B(dx + 1)
+          static_for16<CT>([&](auto tc) { FETCH_A(dx + 1, decltype(tc)::value) });
+        }
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-          acc[i][t] = E::mfma(a[t], bv[i], acc[i][t]);
-    }
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i) acc[i][t] = E::mfma(a[dx & 1][t], bv[dx & 1][i], acc[i][t]);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      });
+#undef FETCH_A
+#undef FETCH_B
 
-    if (has_next) STORE_W((s + 1) & 1);
-    if (next_chunk) STORE_X((chunk + 1) & 1);
-    __syncthreads();
+      if constexpr (XE1 > 0 && dy == KS - 2) {
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) STORE_X(par ^ 1, 0, XE1);
+      }
+      if (has_next) {
+        STORE_W(sbuf ^ 1);
+        if constexpr (dy == KS - 1) STORE_X(par ^ 1, XE1, XE);
+      }
+      __syncthreads();
+    });
   }
 #undef LOAD_X
 #undef STORE_X
 #undef LOAD_W
 #undef STORE_W
+  CODON_TSTAMP(p.dbg, 3)
 
-  // epilogue.  The flag tests are hoisted into four wave-uniform variants so that inside a variant every
-  // residual / accumulate load is unconditional and the 16 loads of a tile are issued back to back (a per-element
-  // `if (flag) v += rg[..]` compiles to a load + vmcnt(0) per element).
+  // epilogue.  Lane term of every output address: pixel (row of this wave's segment i, column l31) of cout plane
+  // 4*half; the cout term (t, r) is wave-uniform and goes into the SGPR offset.  Off-image pixels are out of range.
   const int gx = tx0 + l31;
+  unsigned vo[PSEG];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i) {
+    const int gy = ty0 + wave * PSEG + i;
+    vo[i] = (gx < W && gy < H) ? (unsigned)(4 * half) * HW2 + 2u * (unsigned)(gy * W + gx) : BUF16_OOB;
+  }
+  const bool relu = p.flags & CODON_CONV_RELU;
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)(FUSE ? 64 : COUT) * HW2), BUF16_FLAGS);
+  auto cplane = [&](int t, int r) { return (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW2; };
+
   if constexpr (FUSE) {
     // Chained 1x1 from the accumulators: registers 8g..8g+7 of a 32x32 D tile, rounded to 16 bits (exactly the
     // values the unfused path would have stored and reloaded), are the 8 k-values a lane feeds to the next
     // 32x32x16 MFMA as its B operand -- channels t*32 + 16g + {0,1,2,3,8,9,10,11} + 4*half; the packer permutes
     // W1 to that k order.  16 MFMAs per pixel row instead of a second kernel and an HBM round trip.
-    static_assert(!FUSE || (COUT == 128 && COUTB == 128), "chained 1x1 is 128 -> 64");
-    const bool relu = p.flags & CODON_CONV_RELU;
+    static_assert(!FUSE || COUT == 128, "chained 1x1 is 128 -> 64");
     vec8 pk[PSEG][CT][2];
 #pragma unroll
     for (int i = 0; i < PSEG; ++i)
@@ -266,31 +332,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float v = acc[i][t][8 * g + j];
-            h8[j] = E::from_f32(relu ? fmaxf(v, 0.f) : v);
+            h8[j] = E::from_f32(relu ? relu1_16(v) : v);
           }
           pk[i][t][g] = *reinterpret_cast<const vec8*>(h8);
         }
-    if (p.y && gx < W) {
-      u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base;
+    if (p.y) {
+      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW2), BUF16_FLAGS);
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
+      for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-          for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              const u16* h8 = reinterpret_cast<const u16*>(&pk[i][t][g]);
+          for (int g = 0; g < 2; ++g) {
+            const u16* h8 = reinterpret_cast<const u16*>(&pk[i][t][g]);
 #pragma unroll
-              for (int j = 0; j < 8; ++j)
-                yg[(t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * half) * HW + (long)gy * W + gx] = h8[j];
-            }
-        }
-      }
+            for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b16(h8[j], yrsrc, vo[i], cplane(t, 8 * g + j), 0);
+          }
     }
-    const uint4* __restrict__ w2 = p.w2 + lane;
-    u16* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
-    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 2, BUF16_FLAGS);
+    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(64u * HW2), BUF16_FLAGS);
+    const unsigned w2vo = (unsigned)lane * 16u;
     f32x16 d[2][PSEG];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -302,86 +365,85 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
       for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const uint4 av = w2[((t2 * CT + t) * 2 + g) * 64];
+          const auto av = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2vo, (unsigned)(((t2 * CT + t) * 2 + g) * 1024), 0);
           const vec8 a = *reinterpret_cast<const vec8*>(&av);
 #pragma unroll
           for (int i = 0; i < PSEG; ++i) d[t2][i] = E::mfma(a, pk[i][t][g], d[t2][i]);
         }
     }
-    if (gx < W) {
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
-          const long pix = (long)gy * W + gx;
+    for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-          for (int t2 = 0; t2 < 2; ++t2) {
-            if (rg) {
-              float rv[16];
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (p.res) {
+          float rv[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = E::to_f32(rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
+          for (int r = 0; r < 16; ++r) rv[r] = E::to_f32(__builtin_amdgcn_raw_buffer_load_b16(rrsrc, vo[i], cplane(t2, r), 0));
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = E::from_f32(d[t2][i][r] + rv[r]);
-            } else {
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b16(E::from_f32(d[t2][i][r] + rv[r]), y2rsrc, vo[i], cplane(t2, r), 0);
+        } else {
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = E::from_f32(d[t2][i][r]);
-            }
-          }
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b16(E::from_f32(d[t2][i][r]), y2rsrc, vo[i], cplane(t2, r), 0);
+        }
+      }
+    CODON_TSTAMP(p.dbg, 4)
+    return;
+  }
+
+  // ReLU / residual / accumulate as compile-time variants selected by wave-uniform branches
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW2), BUF16_FLAGS);
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    constexpr int RES = decltype(res_c)::value;
+    constexpr bool ACC = decltype(acc_c)::value;
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        u16 rv[16], av[16];
+        if constexpr (RES != RES16_NONE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = __builtin_amdgcn_raw_buffer_load_b16(rrsrc, vo[i], cplane(t, r), 0);
+        }
+        if constexpr (ACC) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) av[r] = __builtin_amdgcn_raw_buffer_load_b16(yrsrc, vo[i], cplane(t, r), 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][t][r];
+          if constexpr (RELU) v = relu1_16(v);
+          if constexpr (RES == RES16_ADD) v += E::to_f32(rv[r]);
+          if constexpr (RES == RES16_MASK) v = E::to_f32(rv[r]) > 0.f ? v : 0.f;
+          if constexpr (ACC) v += E::to_f32(av[r]);
+          __builtin_amdgcn_raw_buffer_store_b16(E::from_f32(v), yrsrc, vo[i], cplane(t, r), 0);
         }
       }
     }
-    return;
-  }
-  if (gx < W) {
-    u16* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
-    const u16* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
-    const bool relu = p.flags & CODON_CONV_RELU;
-    const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
-    const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
-    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
-    auto epi = [&](auto has_r, auto has_acc) {
-#pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
-          const long pix = (long)gy * W + gx;
-#pragma unroll
-          for (int t = 0; t < CT; ++t) {
-            float rv[16], av[16];
-            if constexpr (decltype(has_r)::value) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                rv[r] = E::to_f32(rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
-            }
-            if constexpr (decltype(has_acc)::value) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                av[r] = E::to_f32(yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float v = acc[i][t][r];
-              if (relu) v = fmaxf(v, 0.f);
-              if constexpr (decltype(has_r)::value) {
-                if (addr) v += rv[r];
-                if (mask) v = rv[r] > 0.f ? v : 0.f;
-              }
-              if constexpr (decltype(has_acc)::value) v += av[r];
-              yg[co * HW + pix] = E::from_f32(v);
-            }
-          }
-        }
-      }
-    };
-    const bool has_r = addr || mask;
-    if (has_r && accum) epi(std::true_type{}, std::true_type{});
-    else if (has_r) epi(std::true_type{}, std::false_type{});
-    else if (accum) epi(std::false_type{}, std::true_type{});
-    else epi(std::false_type{}, std::false_type{});
-  }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using R0 = std::integral_constant<int, RES16_NONE>;
+  using R1 = std::integral_constant<int, RES16_ADD>;
+  using R2 = std::integral_constant<int, RES16_MASK>;
+  const int res_mode = !p.res ? RES16_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RES16_MASK
+                                           : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RES16_ADD : RES16_NONE;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  auto by_acc = [&](auto relu_c, auto res_c) {
+    if (accum) epi(relu_c, res_c, T{});
+    else epi(relu_c, res_c, F{});
+  };
+  auto by_res = [&](auto relu_c) {
+    if (res_mode == RES16_NONE) by_acc(relu_c, R0{});
+    else if (res_mode == RES16_ADD) by_acc(relu_c, R1{});
+    else by_acc(relu_c, R2{});
+  };
+  if (relu) by_res(T{});
+  else by_res(F{});
+  CODON_TSTAMP(p.dbg, 4)
 }
 
 // ---- 1x1 convolution (confuse / confuse_c / confuse_fuse and their dgrad): HBM-bound -----------------
@@ -659,7 +721,10 @@ static int launch_chain16(const codon_conv_desc* d, const void* x, const void* w
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
   p.flags = d->flags;
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, 128, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+#ifdef CODON_TIMING
+  p.dbg = codon_dbg_ptr();
+#endif
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel<fused 1x1>");
 }
 
@@ -671,7 +736,7 @@ int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w,
                                : launch_chain16<EBf16>(d, x, w, y, w_chain, out, res, stream);
 }
 
-template <class E, int KS, int CIN, int COUT, int COUTB = COUT>
+template <class E, int KS, int CIN, int COUT>
 static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
                          hipStream_t stream) {
   Conv16Params p;
@@ -682,12 +747,17 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + 7) / 8;
-  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch * (COUT / COUTB);
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  CODON_REQUIRE(HW * 2 * 128 < (long)BUF16_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+#ifdef CODON_TIMING
+  p.dbg = codon_dbg_ptr();
+#endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT, COUTB>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel");
 }
 
@@ -696,7 +766,7 @@ static int conv2d_fwd_16(const codon_conv_desc* d, const void* x, const void* w,
                          hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
-    case 5128128: return launch_conv16<E, 5, 128, 128>(d, x, w, y, res, stream);  // COUTB = 64 measured 4 % slower
+    case 5128128: return launch_conv16<E, 5, 128, 128>(d, x, w, y, res, stream);
     case 5064064: return launch_conv16<E, 5, 64, 64>(d, x, w, y, res, stream);
     case 3064064: return launch_conv16<E, 3, 64, 64>(d, x, w, y, res, stream);
     case 3128064: return launch_conv16<E, 3, 128, 64>(d, x, w, y, res, stream);

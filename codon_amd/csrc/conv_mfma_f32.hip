@@ -40,6 +40,9 @@ struct ConvParams {
   long x_base, y_base, r_base;  // channel offset * H * W
   int tiles_x, tiles_y, nblk;
   int flags;
+#ifdef CODON_TIMING
+  long long* dbg;
+#endif
   // FUSE only: the chained 1x1 (128 -> 64) applied to the tile while it is still in the accumulators
   const float* w2;  // [t2][t][lane][16]: W1[t2*32 + (lane&31)][t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
   float* y2;
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
+  CODON_TSTAMP(p.dbg, 0)
   unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
   const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   LOAD_W(0);
   STORE_X(0);
   STORE_W(0);
+  CODON_TSTAMP(p.dbg, 1)
   __syncthreads();
+  CODON_TSTAMP(p.dbg, 2)
 
 #pragma unroll 1
   for (int s = 0; s < NST; ++s) {
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 #undef STORE_X
 #undef LOAD_W
 #undef STORE_W
+  CODON_TSTAMP(p.dbg, 3)
 
   // epilogue.  Lane term of every output address: pixel (row of this wave's segment i, column l31) of cout plane
   // 4*half; the cout term (t, r) is wave-uniform and goes into the SGPR offset.  Off-image pixels -> BUF_OOB.
@@ -325,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
           for (int r = 0; r < 16; ++r) buf_st(d[i][r], y2rsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
       }
     }
+    CODON_TSTAMP(p.dbg, 4)
     return;
   }
 
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   };
   if (relu) by_res(T{});
   else by_res(F{});
+  CODON_TSTAMP(p.dbg, 4)
 }
 
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
@@ -436,6 +445,9 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
                 "conv2d_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+#ifdef CODON_TIMING
+  p.dbg = codon_dbg_ptr();
+#endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel");
@@ -464,6 +476,9 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
                 "conv_chain1x1_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
+#ifdef CODON_TIMING
+  p.dbg = codon_dbg_ptr();
+#endif
   hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");
 }
