@@ -223,20 +223,42 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
 #undef LOAD_W
 #undef STORE_W
 
+  // epilogue: buffer stores -- wave-uniform cout-plane term in the SGPR offset, one hoisted VGPR offset per pixel
+  // row, off-image pixels out of range (dropped); see conv_mfma_f32.hip.
   const int gx = tx0 + l31;
+  const unsigned HW4 = 4u * (unsigned)H * (unsigned)W;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned vo[PSEG];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i) {
+    const int gy = ty0 + wave * PSEG + i;
+    vo[i] = (gx < W && gy < H) ? (unsigned)(4 * half) * HW4 + 4u * (unsigned)(gy * W + gx) : OOB;
+  }
+  auto cplane = [&](int t, int r) { return (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4; };
+  auto relu1 = [](float v) { float o; asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(v)); return o; };
+  auto ld = [](__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v, so, 0));
+  };
+  auto st = [](float x, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, v, so, 0);
+  };
+  const bool relu = p.flags & CODON_CONV_RELU;
+  constexpr float unscale = 1.f / (float)(1 << F3_WSCALE_LOG2);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base + (FUSE ? 0 : (long)cob * COUTB * HW) : p.x), 0,
+      (int)((unsigned)(FUSE ? 64 : COUTB) * HW4), 0x00020000);
+
   if constexpr (FUSE) {
     // Chained 1x1: the fp32 tile (unscaled, ReLU'd) is split into fp16 hi + lo in registers -- registers 8g..8g+7
     // of a D tile are the 8 k-values of the next MFMA's B operand -- and multiplied by the split, 2^10-scaled W1
     // with the same three products as the main loop.
     static_assert(!FUSE || COUTB == 128, "chained 1x1 is 128 -> 64");
-    const bool relu = p.flags & CODON_CONV_RELU;
-    constexpr float unscale = 1.f / (float)(1 << F3_WSCALE_LOG2);
-    float* __restrict__ yg = p.y ? p.y + (long)b * p.y_img + p.y_base : nullptr;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y ? p.y + (long)b * p.y_img + p.y_base : p.y2), 0, (int)(128u * HW4), 0x00020000);
     f16x8 bh[PSEG][CT][2], bl[PSEG][CT][2];
 #pragma unroll
     for (int i = 0; i < PSEG; ++i) {
-      const int gy = ty0 + wave * PSEG + i;
-      const bool st = yg && gx < W && gy < H;
+      const unsigned voy = p.y ? vo[i] : OOB;
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -245,8 +267,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = acc[i][t][8 * g + j] * unscale;
-            if (relu) v = fmaxf(v, 0.f);
-            if (st) yg[(t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * half) * HW + (long)gy * W + gx] = v;
+            if (relu) v = relu1(v);
+            st(v, yrsrc, voy, cplane(t, 8 * g + j));
             h8[j] = f2h_bits(v);
             l8[j] = f2h_bits(v - h2f_bits(h8[j]));
           }
@@ -254,9 +276,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
           bl[i][t][g] = *reinterpret_cast<const f16x8*>(l8);
         }
     }
-    const uint4* __restrict__ w2 = p.w2 + lane;
-    float* __restrict__ y2 = p.y2 + (long)b * p.y2_img + p.y2_base;
-    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base : nullptr;
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(64u * HW4), 0x00020000);
+    const unsigned w2vo = (unsigned)lane * 16u;
 #pragma unroll 1
     for (int t2 = 0; t2 < 2; ++t2) {
       f32x16 d[PSEG];
@@ -268,8 +291,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
       for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const uint4 hv = w2[(((t2 * CT + t) * 2 + g) * 2 + 0) * 64];
-          const uint4 lv = w2[(((t2 * CT + t) * 2 + g) * 2 + 1) * 64];
+          const unsigned so = (unsigned)((((t2 * CT + t) * 2 + g) * 2) * 1024);
+          const auto hv = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2vo, so, 0);
+          const auto lv = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2vo, so + 1024u, 0);
           const f16x8 ah = *reinterpret_cast<const f16x8*>(&hv), al = *reinterpret_cast<const f16x8*>(&lv);
 #pragma unroll
           for (int i = 0; i < PSEG; ++i) {
@@ -278,77 +302,74 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
             d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][t][g], d[i], 0, 0, 0);
           }
         }
-      if (gx < W) {
+      if (p.res) {
 #pragma unroll
         for (int i = 0; i < PSEG; ++i) {
-          const int gy = ty0 + wave * PSEG + i;
-          if (gy < H) {
-            const long pix = (long)gy * W + gx;
-            if (rg) {
-              float rv[16];
+          float rv[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = rg[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
+          for (int r = 0; r < 16; ++r) rv[r] = ld(rrsrc, vo[i], cplane(t2, r));
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] * unscale + rv[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                y2[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix] = d[i][r] * unscale;
-            }
-          }
+          for (int r = 0; r < 16; ++r) st(d[i][r] * unscale + rv[r], y2rsrc, vo[i], cplane(t2, r));
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st(d[i][r] * unscale, y2rsrc, vo[i], cplane(t2, r));
       }
     }
     return;
   }
-  if (gx < W) {
-    float* __restrict__ yg = p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW;
-    const float* __restrict__ rg = p.res ? p.res + (long)b * p.r_img + p.r_base + (long)cob * COUTB * HW : nullptr;
-    const bool relu = p.flags & CODON_CONV_RELU;
-    const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
-    const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
-    const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
-    constexpr float unscale = 1.f / (float)(1 << F3_WSCALE_LOG2);
-    auto epi = [&](auto has_r, auto has_acc) {
+
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long)b * p.y_img + p.y_base + (long)cob * COUTB * HW), 0, (int)((unsigned)COUTB * HW4), 0x00020000);
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    constexpr int RES = decltype(res_c)::value;   // 0 none, 1 add, 2 mask
+    constexpr bool ACC = decltype(acc_c)::value;
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i) {
-        const int gy = ty0 + wave * PSEG + i;
-        if (gy < H) {
-          const long pix = (long)gy * W + gx;
+    for (int i = 0; i < PSEG; ++i) {
 #pragma unroll
-          for (int t = 0; t < CT; ++t) {
-            float rv[16], av[16];
-            if constexpr (decltype(has_r)::value) {
+      for (int t = 0; t < CT; ++t) {
+        float rv[16], av[16];
+        if constexpr (RES != 0) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
-            }
-            if constexpr (decltype(has_acc)::value) {
+          for (int r = 0; r < 16; ++r) rv[r] = ld(rrsrc, vo[i], cplane(t, r));
+        }
+        if constexpr (ACC) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) av[r] = yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pix];
-            }
+          for (int r = 0; r < 16; ++r) av[r] = ld(yrsrc, vo[i], cplane(t, r));
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float v = acc[i][t][r] * unscale;
-              if (relu) v = fmaxf(v, 0.f);
-              if constexpr (decltype(has_r)::value) {
-                if (addr) v += rv[r];
-                if (mask) v = rv[r] > 0.f ? v : 0.f;
-              }
-              if constexpr (decltype(has_acc)::value) v += av[r];
-              yg[co * HW + pix] = v;
-            }
-          }
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][t][r] * unscale;
+          if constexpr (RELU) v = relu1(v);
+          if constexpr (RES == 1) v += rv[r];
+          if constexpr (RES == 2) v = rv[r] > 0.f ? v : 0.f;
+          if constexpr (ACC) v += av[r];
+          st(v, yrsrc, vo[i], cplane(t, r));
         }
       }
-    };
-    const bool has_r = addr || mask;
-    if (has_r && accum) epi(std::true_type{}, std::true_type{});
-    else if (has_r) epi(std::true_type{}, std::false_type{});
-    else if (accum) epi(std::false_type{}, std::true_type{});
-    else epi(std::false_type{}, std::false_type{});
-  }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  const int res_mode = !p.res ? 0 : (p.flags & CODON_CONV_MASK_RELU) ? 2 : (p.flags & CODON_CONV_ADD_RESIDUAL) ? 1 : 0;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  auto by_acc = [&](auto relu_c, auto res_c) {
+    if (accum) epi(relu_c, res_c, T{});
+    else epi(relu_c, res_c, F{});
+  };
+  auto by_res = [&](auto relu_c) {
+    if (res_mode == 0) by_acc(relu_c, R0{});
+    else if (res_mode == 1) by_acc(relu_c, R1{});
+    else by_acc(relu_c, R2{});
+  };
+  if (relu) by_res(T{});
+  else by_res(F{});
 }
 
 // OIHW fp32 -> [cout64 block][chunk][dy][part][dx][cb (2)][64 cout][8 ch] fp16, scaled by 2^10, split hi/lo
@@ -435,6 +456,8 @@ static int launch_s3(const codon_conv_desc* d, const float* x, const void* w, fl
   p.ncob = d->cout / COUTB;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch * p.ncob;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  CODON_REQUIRE(HW * 4 * 128 < 0xFFFFFFF0L, CODON_ERR_UNSUPPORTED,
+                "conv2d_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
