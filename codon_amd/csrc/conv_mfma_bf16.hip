@@ -482,14 +482,6 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
   const long pix0 = (((long)blockIdx.x * C1_ITER + it) * 4 + wave) * 64;   // first pixel of this wave's group
   if (pix0 >= HW) break;                                   // wave-uniform
 
-  f32x16 acc[2][CT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
-
   // PAIRED: this lane's pixel pair starts at pp (tile 0 = pp, tile 1 = pp + 1); else tile i pixel = px[i]
   const long pp = pix0 + 2 * l31;
   const bool pok = pp < HW;                                // HW even: both pixels in or out together
@@ -519,14 +511,8 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
       }
     }
   }
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    vec8 a[CT], bv[2];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-      const uint4 v = wg[(ks * 2 + half) * COUT + t * 32 + l31];
-      a[t] = *reinterpret_cast<const vec8*>(&v);
-    }
+  // B fragments of k-step ks from the raw words (rebuilt per cout half: a few VALU ops, fewer live registers)
+  auto make_bv = [&](const int ks, vec8* bv) {
     if constexpr (PAIRED) {
       unsigned e[4], o[4];
 #pragma unroll
@@ -551,55 +537,82 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
         bv[i] = *reinterpret_cast<const vec8*>(&v);
       }
     }
+  };
+  // The COUT rows are processed CTB tiles (64 couts) at a time: the residual / mask / accumulate words of a half are
+  // requested BEFORE its MFMAs, so a wave makes one memory round trip per half (the all-CT version with its
+  // register-limited one-tile batches made CT + 1 serialized trips: the 64 -> 128 dgrad ran at 1.9 TB/s).
+  constexpr int CTB = CT > 2 ? 2 : CT;
+  auto half_pass = [&](auto has_r, auto has_acc, const int t0) {
+    unsigned rm[CTB][16], am[CTB][16];      // PAIRED: one word = the lane's pixel pair; else [i * 8 + ..] halves
+    u16 rs[PAIRED ? 1 : 2][CTB][16], as[PAIRED ? 1 : 2][CTB][16];
+    auto fetch_words = [&]() {
+    if constexpr (PAIRED) {
+      if constexpr (decltype(has_r)::value) {
+#pragma unroll
+        for (int g = 0; g < CTB; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rm[g][r] = *reinterpret_cast<const unsigned*>(rg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + (pok ? pp : 0));
+      }
+      if constexpr (decltype(has_acc)::value) {
+#pragma unroll
+        for (int g = 0; g < CTB; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            am[g][r] = *reinterpret_cast<const unsigned*>(yg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + (pok ? pp : 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < CTB; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long o = ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + (ok[i] ? px[i] : 0);
+            if constexpr (decltype(has_r)::value) rs[i][g][r] = rg[o];
+            if constexpr (decltype(has_acc)::value) as[i][g][r] = yg[o];
+          }
+    }
+    };
+    if constexpr (CT > 2) fetch_words();   // two passes: request this half's words ahead of its MFMAs
+    f32x16 acc[2][CTB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
-        acc[i][t] = E::mfma(a[t], bv[i], acc[i][t]);
-  }
-
-  // epilogue: flag tests hoisted into wave-uniform variants; inside a variant the 16 residual / accumulate loads
-  // of a cout tile are unconditional and issued back to back (see conv_mfma_bf16_kernel)
-  auto epi = [&](auto has_r, auto has_acc) {
+      for (int g = 0; g < CTB; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      vec8 a[CTB], bv[2];
+#pragma unroll
+      for (int g = 0; g < CTB; ++g) {
+        const uint4 v = wg[(ks * 2 + half) * COUT + (t0 + g) * 32 + l31];
+        a[g] = *reinterpret_cast<const vec8*>(&v);
+      }
+      make_bv(ks, bv);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < CTB; ++g) acc[i][g] = E::mfma(a[g], bv[i], acc[i][g]);
+    }
+    if constexpr (CT <= 2) fetch_words();  // single pass: after the MFMAs (fewer live registers; measured faster)
     if constexpr (PAIRED) {
       if (pok) {
-        // residual / accumulate words are loaded G cout tiles at a time before the stores of that group:
-        // G = CT when the registers allow it (CT = 2: 32 + 32 words), else one tile (16 + 16) at a time
-        constexpr int G = (CT <= 2) ? CT : 1;
 #pragma unroll
-        for (int t0 = 0; t0 < CT; t0 += G) {
-          unsigned rm[G][16], am[G][16];
-          if constexpr (decltype(has_r)::value) {
+        for (int g = 0; g < CTB; ++g) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                rm[g][r] = *reinterpret_cast<const unsigned*>(rg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pp);
-          }
-          if constexpr (decltype(has_acc)::value) {
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                am[g][r] = *reinterpret_cast<const unsigned*>(yg + ((t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + pp);
-          }
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int t = t0 + g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float v0 = acc[0][t][r], v1 = acc[1][t][r];
-              if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-              if constexpr (decltype(has_r)::value) {
-                const float m0 = E::lo(rm[g][r]), m1 = E::hi(rm[g][r]);
-                if (addr) { v0 += m0; v1 += m1; }
-                if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
-              }
-              if constexpr (decltype(has_acc)::value) { v0 += E::lo(am[g][r]); v1 += E::hi(am[g][r]); }
-              *reinterpret_cast<unsigned*>(yg + co * HW + pp) =
-                  (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+          for (int r = 0; r < 16; ++r) {
+            const int co = (t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v0 = acc[0][g][r], v1 = acc[1][g][r];
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if constexpr (decltype(has_r)::value) {
+              const float m0 = E::lo(rm[g][r]), m1 = E::hi(rm[g][r]);
+              if (addr) { v0 += m0; v1 += m1; }
+              if (mask) { v0 = m0 > 0.f ? v0 : 0.f; v1 = m1 > 0.f ? v1 : 0.f; }
             }
+            if constexpr (decltype(has_acc)::value) { v0 += E::lo(am[g][r]); v1 += E::hi(am[g][r]); }
+            *reinterpret_cast<unsigned*>(yg + co * HW + pp) = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
           }
         }
       }
@@ -608,37 +621,31 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_kernel(const Conv16Params p)
       for (int i = 0; i < 2; ++i) {
         if (!ok[i]) continue;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-          float rv[16], av[16];
-          if constexpr (decltype(has_r)::value) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = E::to_f32(rg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + px[i]]);
-          }
-          if constexpr (decltype(has_acc)::value) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) av[r] = E::to_f32(yg[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * HW + px[i]]);
-          }
+        for (int g = 0; g < CTB; ++g)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[i][t][r];
+            const int co = (t0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][g][r];
             if (relu) v = fmaxf(v, 0.f);
             if constexpr (decltype(has_r)::value) {
-              if (addr) v += rv[r];
-              if (mask) v = rv[r] > 0.f ? v : 0.f;
+              const float m = E::to_f32(rs[i][g][r]);
+              if (addr) v += m;
+              if (mask) v = m > 0.f ? v : 0.f;
             }
-            if constexpr (decltype(has_acc)::value) v += av[r];
+            if constexpr (decltype(has_acc)::value) v += E::to_f32(as[i][g][r]);
             yg[co * HW + px[i]] = E::from_f32(v);
           }
-        }
       }
     }
   };
   const bool has_r = addr || mask;
-  if (has_r && accum) epi(std::true_type{}, std::true_type{});
-  else if (has_r) epi(std::true_type{}, std::false_type{});
-  else if (accum) epi(std::false_type{}, std::true_type{});
-  else epi(std::false_type{}, std::false_type{});
+#pragma unroll
+  for (int t0 = 0; t0 < CT; t0 += CTB) {
+    if (has_r && accum) half_pass(std::true_type{}, std::true_type{}, t0);
+    else if (has_r) half_pass(std::true_type{}, std::false_type{}, t0);
+    else if (accum) half_pass(std::false_type{}, std::true_type{}, t0);
+    else half_pass(std::false_type{}, std::false_type{}, t0);
+  }
   }  // it
 }
 
