@@ -10,8 +10,9 @@
 //   xs[cb][row][col] : 16-byte elements = 8 channels of one pixel (NHWC-within-8);  B fragment of a
 //                      half-wave = 32 consecutive elements of one tile row  -> conflict-free ds_read_b128
 //   ws[dx][cb][cout] : 16-byte elements = 8 input channels of one (tap, cout);      A fragment likewise
-// HBM stays NCHW (coalesced along W); the channel-blocking transpose happens while staging: each thread
-// loads two channels of a pixel run, packs them to 32-bit words and writes them into the blocked image.
+// HBM stays NCHW (coalesced along W); the channel-blocking transpose happens while staging: a thread owns one
+// 16-byte element (8 channels of one pixel), loads its 8 channel planes with 8 two-byte buffer loads (a wave = 64
+// consecutive pixels of one plane per instruction) and writes the element with one conflict-free ds_write_b128.
 // The packed weight image is produced once per weight version in exactly the ws stage order.
 //
 // K loop: stages = (chunk of 16 channels, filter row dy): KS taps x 1 MFMA k-step x (2 pixel rows x COUT/32)
