@@ -105,13 +105,18 @@ __device__ __forceinline__ float relu1_16(float v) {   // one v_max (fmaxf adds 
 
 enum { RES16_NONE = 0, RES16_ADD = 1, RES16_MASK = 2 };
 
+// pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is 8 MFMAs
+// on 6 operand fetches (0.75 ds_read_b128 per MFMA instead of 1.0 -- LDS bandwidth is what these kernels run out of)
+// Measured A/B on one box: conv5x5 64->64 2.21 -> 2.05 ms; the 3x3 convs (3 taps per stage) do not gain (1.09 -> 1.10).
+template <int KS, int COUT> struct Conv16Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : 2; };
+
 template <class E, int KS, int CIN, int COUT, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
   typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
   constexpr int PAD = KS / 2;
-  constexpr int PSEG = 2;
+  constexpr int PSEG = Conv16Pseg<KS, COUT>::value;
   constexpr int TW = 32, TH = 4 * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = 16, NCB = CK / 8;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
       // Operand fetch one filter tap ahead of its MFMAs, in two register sets.  PIN: sched_barrier holds that order
       // (the scheduler otherwise sinks every fetch down to its use) -- measured on one box (A/B, same call): pinned
       // wins on the 8-MFMA taps of conv5x5-128 (6.59 vs 6.75 ms), unpinned on the 3x3 convs (1.13 vs 1.21 ms).
-      constexpr bool PIN = (KS == 5 && CT == 4);
+      constexpr bool PIN = (KS == 5 && PSEG * CT == 8);
       vec8 a[2][CT], bv[2][PSEG];
 #define FETCH_A(dx_, t_)                                                                                  \
   {                                                                                                       \
@@ -753,8 +758,9 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   const long HW = (long)d->height * d->width;
   p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = d->r_ctotal * HW;
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = d->r_coff * HW;
+  constexpr int TH = 4 * Conv16Pseg<KS, COUT>::value;
   p.tiles_x = (d->width + 31) / 32;
-  p.tiles_y = (d->height + 7) / 8;
+  p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   CODON_REQUIRE(HW * 2 * 128 < (long)BUF16_OOB, CODON_ERR_UNSUPPORTED,
