@@ -126,11 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   const int b = bid / p.tiles_y;
   const int tx0 = tx * TW, ty0 = ty * TH;
   const int H = p.H, W = p.W;
-  const unsigned HW4 = 4u * (unsigned)H * (unsigned)W;   // bytes per channel plane (launcher: 128 planes < 4 GiB)
+  const unsigned HW4 = 4u * (unsigned)H * (unsigned)W;   // bytes per channel plane (launcher: 32 planes < 4 GiB)
+  const long HWl = (long)H * W;
+  // descriptor over planes [plane, plane + n) of a slice: the 64-bit part of every address is SALU work, done once
+  // per chunk / cout tile; what is left for the VGPR + SGPR offsets stays below 32 planes
+  auto planes = [&](const float* base, int plane, int n) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)plane * HWl), 0, (int)((unsigned)n * HW4), BUF_FLAGS);
+  };
 
   // wave-uniform buffer descriptors: this image's input slice, the packed weights
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)CIN * HW4), BUF_FLAGS);
+  const float* const xbase = p.x + (long)b * p.x_img + p.x_base;
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 4), BUF_FLAGS);
 
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 // staging steps as macros (not lambdas): keeps xr/wr in registers (no alloca left for scratch)
 #define LOAD_X(chunk_)                                                             \
   {                                                                                \
-    const unsigned so_ = (unsigned)(chunk_) * (unsigned)CK * HW4;                  \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xrsrc, xoff[k], so_); \
+    const __amdgpu_buffer_rsrc_t xr_ = planes(xbase, (chunk_) * CK, CK);           \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xr_, xoff[k], 0u); \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \
@@ -260,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
     vo[i] = (gx < W && gy < H) ? (unsigned)(4 * half) * HW4 + 4u * (unsigned)(gy * W + gx) : BUF_OOB;
   }
   const bool relu = p.flags & CODON_CONV_RELU;
-  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)(FUSE ? 64 : COUT) * HW4), BUF_FLAGS);
+  const float* const rbase = p.res ? p.res + (long)b * p.r_img + p.r_base : p.x;
+  auto inplane = [&](int r) { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW4; };   // cout plane inside a 32-cout tile
 
   if constexpr (FUSE) {
     // Chained 1x1: the D layout of the 32x32 MFMA (lane = pixel l&31, register r = channel (r&3)+8(r>>2)+4(l>>5))
@@ -279,19 +284,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
           for (int r = 0; r < 16; ++r) acc[i][t][r] = relu1(acc[i][t][r]);
     }
     if (p.y) {
-      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW4), BUF_FLAGS);
+      const float* const ybase = p.y + (long)b * p.y_img + p.y_base;
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i)
+      for (int t = 0; t < CT; ++t) {
+        const __amdgpu_buffer_rsrc_t yr_ = planes(ybase, t * 32, 32);
 #pragma unroll
-        for (int t = 0; t < CT; ++t)
+        for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            buf_st(acc[i][t][r], yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) buf_st(acc[i][t][r], yr_, vo[i], inplane(r));
+      }
     }
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(64u * HW4), BUF_FLAGS);
+    const float* const y2base = p.y2 + (long)b * p.y2_img + p.y2_base;
     const unsigned w2vo = (unsigned)lane * 64u;
 #pragma unroll 1
     for (int t2 = 0; t2 < 2; ++t2) {
@@ -315,21 +319,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
           for (int i = 0; i < PSEG; ++i)
             d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[i][t][r], d[i], 0, 0, 0);
       }
-      const unsigned so2 = (unsigned)(t2 * 32) * HW4;
+      const __amdgpu_buffer_rsrc_t y2rsrc = planes(y2base, t2 * 32, 32), rrsrc = planes(rbase, t2 * 32, 32);
       if (p.res) {
 #pragma unroll
         for (int i = 0; i < PSEG; ++i) {
           float rv[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], inplane(r));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) buf_st(d[i][r] + rv[r], y2rsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) buf_st(d[i][r] + rv[r], y2rsrc, vo[i], inplane(r));
         }
       } else {
 #pragma unroll
         for (int i = 0; i < PSEG; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) buf_st(d[i][r], y2rsrc, vo[i], so2 + (unsigned)((r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) buf_st(d[i][r], y2rsrc, vo[i], inplane(r));
       }
     }
     CODON_TSTAMP(p.dbg, 4)
@@ -338,24 +342,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 
   // ReLU / residual / accumulate as compile-time variants selected by wave-uniform branches: inside a variant every
   // element costs its store plus at most two VALU ops, and the 16 loads of a tile are issued back to back.
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)COUT * HW4), BUF_FLAGS);
+  const float* const ybase = p.y + (long)b * p.y_img + p.y_base;
   auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int RES = decltype(res_c)::value;
     constexpr bool ACC = decltype(acc_c)::value;
 #pragma unroll
-    for (int i = 0; i < PSEG; ++i) {
+    for (int t = 0; t < CT; ++t) {
+      const __amdgpu_buffer_rsrc_t yrsrc = planes(ybase, t * 32, 32), rrsrc = planes(rbase, t * 32, 32);
 #pragma unroll
-      for (int t = 0; t < CT; ++t) {
+      for (int i = 0; i < PSEG; ++i) {
         float rv[16], av[16];
         if constexpr (RES != RES_NONE) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rrsrc, vo[i], inplane(r));
         }
         if constexpr (ACC) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) av[r] = buf_ld(yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+          for (int r = 0; r < 16; ++r) av[r] = buf_ld(yrsrc, vo[i], inplane(r));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
           if constexpr (RES == RES_ADD) v += rv[r];
           if constexpr (RES == RES_MASK) v = rv[r] > 0.f ? v : 0.f;
           if constexpr (ACC) v += av[r];
-          buf_st(v, yrsrc, vo[i], (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * HW4);
+          buf_st(v, yrsrc, vo[i], inplane(r));
         }
       }
     }
@@ -441,8 +445,8 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
-  CODON_REQUIRE(HW * 4 * 128 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
-                "conv2d_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  CODON_REQUIRE(HW * 4 * 32 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_fwd: %dx%d image: 32 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
 #ifdef CODON_TIMING
@@ -472,8 +476,8 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: grid too large (%ld blocks)", nblk);
-  CODON_REQUIRE(HW * 4 * 128 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
-                "conv_chain1x1_fwd: %dx%d image: 128 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  CODON_REQUIRE(HW * 4 * 32 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: %dx%d image: 32 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   p.nblk = (int)nblk;
   p.flags = d->flags;
 #ifdef CODON_TIMING

@@ -335,3 +335,23 @@ def test_conv2d_fp16_vs_torch(k, cin, cout):
     y = torch.full((B, cout, H, W), float("nan"), device=dev, dtype=torch.float16)
     ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, relu=True)
     assert rel_rmse(y.float().cpu(), F.relu(ref)) < 5e-4
+
+
+def test_conv2d_plane_larger_than_32bit_slice():
+    """One 3000x3000 image: a 128-channel slice would be 4.6 GB, past a single 32-bit buffer descriptor -- the
+    kernels re-base their descriptors per channel chunk / cout tile.  Checked on three row windows against torch."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    H = W = 3000
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand((1, 128, H, W), generator=g, device=dev) - 0.5
+    w = _rand((64, 128, 3, 3), 6, scale=0.03)
+    y = torch.empty((1, 64, H, W), device=dev)
+    ops.conv2d(Slice(x), ops.packed_weight(w.to(dev)), Slice(y), 3, relu=True)
+    for r0 in (0, 1480, H - 24):
+        lo, hi = max(r0 - 1, 0), min(r0 + 25, H)
+        ref = F.relu(F.conv2d(x[:, :, lo:hi].cpu(), w, None, 1, 1))[:, :, r0 - lo:r0 - lo + 24]
+        assert rel_rmse(y[:, :, r0:r0 + 24].cpu(), ref) < 2e-6
+    del x, y
+    torch.cuda.empty_cache()
