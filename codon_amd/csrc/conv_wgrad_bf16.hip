@@ -301,6 +301,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
 int launch_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
                         hipStream_t stream);
 
+// conv_wgrad_cm16.hip: channel-major tiles, one filter row per wave (W % 8 == 0, 16-byte aligned slices, k in {3,5})
+bool conv_wgrad_cm16_supported(const codon_conv_desc* d, const void* x, const void* gy);
+int launch_wgrad_cm16(const codon_conv_desc* d, const void* x, const void* gy, float* workspace, int tiles_x,
+                      int band_tiles_y, int nbands, int nsplit, int nchan_blocks, hipStream_t stream);
+
 struct Wgrad16Plan {
   int nbands, band_tiles_y, nsplit, nchan_blocks;
 };
@@ -309,12 +314,14 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   const int k = d->ksize, ci = d->cin, co = d->cout;
   if (!((k == 1 || k == 3 || k == 5) && ci % 32 == 0 && co % 64 == 0)) return false;
   pl->nchan_blocks = (co / 64) * (ci / 32);
-  const int tiles_y = (d->height + 3) / 4;
+  // bands are whole multiples of 8 image rows (both kernels' tile heights, 4 and 8, divide them)
+  const int tiles_y8 = (d->height + 7) / 8;
   int want = (512 + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);   // ~2 workgroups per CU
   if (want < 1) want = 1;
-  if (want > tiles_y) want = tiles_y;
-  pl->band_tiles_y = (tiles_y + want - 1) / want;
-  pl->nbands = (tiles_y + pl->band_tiles_y - 1) / pl->band_tiles_y;
+  if (want > tiles_y8) want = tiles_y8;
+  const int band8 = (tiles_y8 + want - 1) / want;
+  pl->nbands = (tiles_y8 + band8 - 1) / band8;
+  pl->band_tiles_y = 2 * band8;                       // in 4-row tiles
   pl->nsplit = d->batch * pl->nbands;
   return true;
 }
@@ -335,6 +342,13 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   CODON_REQUIRE(ws_bytes >= conv_wgrad_bf16_workspace_bytes(d), CODON_ERR_BAD_ARG,
                 "conv2d_wgrad: workspace %zu B < required %zu B", ws_bytes, conv_wgrad_bf16_workspace_bytes(d));
   CODON_REQUIRE(pl.nsplit <= 65535, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: %d splits > 65535", pl.nsplit);
+  static const bool cm_env = getenv("CODON_WGRAD_CM") ? atoi(getenv("CODON_WGRAD_CM")) != 0 : true;
+  if (cm_env && conv_wgrad_cm16_supported(d, x, gy)) {
+    const int st = launch_wgrad_cm16(d, x, gy, workspace, (d->width + 31) / 32, pl.band_tiles_y * 4, pl.nbands, pl.nsplit,
+                                     pl.nchan_blocks, stream);
+    if (st != CODON_OK) return st;
+    return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
+  }
   const long HW = (long)d->height * d->width;
   Wgrad16Params p;
   p.x = (const u16*)x; p.gy = (const u16*)gy; p.ws = workspace;
