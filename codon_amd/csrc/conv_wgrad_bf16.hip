@@ -316,7 +316,9 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   pl->nchan_blocks = (co / 64) * (ci / 32);
   // bands are whole multiples of 8 image rows (both kernels' tile heights, 4 and 8, divide them)
   const int tiles_y8 = (d->height + 7) / 8;
-  int want = (512 + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);   // ~2 workgroups per CU
+  // k = 1 through conv_wgrad_cm16.hip covers 128 cin per workgroup: size the split for that (smaller) grid
+  const int nb = (k == 1 && ci % 128 == 0) ? (co / 64) * (ci / 128) : pl->nchan_blocks;
+  int want = (512 + nb * d->batch - 1) / (nb * d->batch);   // ~2 workgroups per CU
   if (want < 1) want = 1;
   if (want > tiles_y8) want = tiles_y8;
   const int band8 = (tiles_y8 + want - 1) / want;

@@ -16,6 +16,7 @@
 //     the KS fragments in registers: even shift = a register offset, odd shift = four v_alignbit_b32 (VALU is nearly
 //     free beside 16-bit MFMAs).  LDS bytes per MFMA: (1 KB A + 2 KB window) / KS = 614 B for 5x5 (was 1 170 B).
 // Needs W % 8 == 0 and 16-byte aligned slices (the launcher falls back to conv_wgrad_bf16.hip otherwise).
+// k = 1 (confuse*): no margins, no shifts; see KSPLIT below.
 //
 // Workgroup = 2*KS waves = (2 cout tiles) x (KS filter rows): 64 cout x 32 cin x all taps, streaming an image band in
 // CM_TH x 32 pixel tiles, LDS double-buffered.  Partials -> workspace[split][tap][co][ci] (fp32), summed in fixed order by
@@ -41,7 +42,8 @@ struct CmF16 {
 #ifndef CODON_CM_TH
 #define CODON_CM_TH 4
 #endif
-constexpr int CM_TH = CODON_CM_TH;   // tile rows; the launcher's bands are whole multiples of 8 rows
+constexpr int CM_TH = CODON_CM_TH;
+constexpr int CM_CIB1 = 4;          // k = 1: 128 cin per workgroup   // tile rows; the launcher's bands are whole multiples of 8 rows
 
 struct WgradCmParams {
   const unsigned short* x;
@@ -52,22 +54,26 @@ struct WgradCmParams {
   int tiles_x, band_tiles_y, nbands, nsplit;
 };
 
+// KS == 1 has a single "filter row": its 8 waves are (2 cout tiles) x (TH tile rows) instead -- each wave takes the
+// k-steps of one tile row, and the TH partial accumulators are summed through LDS once, after the band.
 template <class E, int KS>
-__global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const WgradCmParams p) {
+__global__ __launch_bounds__(KS == 1 ? 2 * CM_TH * 64 : 2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const WgradCmParams p) {
   typedef typename E::vec8 vec8;
   typedef const __attribute__((address_space(3))) cm_u32x4* lds_r128;
   typedef const __attribute__((address_space(3))) cm_u32x2* lds_r64;
-  constexpr int NT = 2 * KS * 64;
+  constexpr bool KSPLIT = (KS == 1);
+  constexpr int CIB = KSPLIT ? CM_CIB1 : 1;      // 32-cin tiles per workgroup (k = 1 is HBM-bound: gy is re-read per cin block)
+  constexpr int NT = KSPLIT ? 2 * CM_TH * 64 : 2 * KS * 64;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = CM_TH;
-  constexpr int XL = 8;                        // left margin of the x tile: its column origin tx0 - 8 is 16-byte aligned
-  constexpr int XC = XL + TW + 8;              // 48 columns = 6 chunks of 8 pixels
+  constexpr int XL = KSPLIT ? 0 : 8;           // left margin of the x tile: its column origin tx0 - 8 is 16-byte aligned
+  constexpr int XC = XL + TW + (KSPLIT ? 0 : 8);   // 48 columns = 6 chunks of 8 pixels (k = 1: the 32 tile columns)
   constexpr int XR = TH + KS - 1;
   constexpr int XROW = XC * 2;                 // bytes per tile row of one channel
   constexpr int XPITCH = XR * XROW + 16;       // bytes per channel: +16 -> 4 banks per lane step (conflict-free b128 / b64)
   constexpr int GPITCH = TH * TW * 2 + 16;     // bytes per cout row of the gy tile
-  constexpr int XBYTES = 32 * XPITCH, GBYTES = 64 * GPITCH;
-  constexpr int NXC = 32 * XR * (XC / 8);      // 16-byte chunks of the x tile
+  constexpr int XBYTES = 32 * CIB * XPITCH, GBYTES = 64 * GPITCH;
+  constexpr int NXC = 32 * CIB * XR * (XC / 8);      // 16-byte chunks of the x tile
   constexpr int NGC = 64 * TH * (TW / 8);
   constexpr int XE = (NXC + NT - 1) / NT, GE = (NGC + NT - 1) / NT;
   constexpr int NK = TH * (TW / 16);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
   const long HW = (long)H * W;
   const unsigned HW2 = 2u * (unsigned)H * (unsigned)W;
 
-  const int nci_t = p.cin / 32;
+  const int nci_t = p.cin / (32 * CIB);
   const int cob = blockIdx.x / nci_t, cib = blockIdx.x % nci_t;   // 64-cout block, 32-cin block
   const int split = blockIdx.y;
   const int b = split / p.nbands, band = split % p.nbands;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
   const int ty_end = min(ty_begin + p.band_tiles_y, tiles_y);
   const int ntile = (ty_end - ty_begin) * p.tiles_x;
 
-  const unsigned short* const xg = p.x + b * p.x_img + p.x_base + (long)cib * 32 * HW;
+  const unsigned short* const xg = p.x + b * p.x_img + p.x_base + (long)cib * 32 * CIB * HW;
   const unsigned short* const gg = p.gy + b * p.g_img + p.g_base + (long)cob * 64 * HW;
 
   // staging plan (tile independent): chunk e = tid + NT k
@@ -117,13 +123,15 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
     glds[k] = in ? c * GPITCH + (r * TW + ch * 8) * 2 : 0;
   }
 
-  const int co_t = wave & 1, dy = wave >> 1;
+  const int co_t = wave & 1, dy = KSPLIT ? 0 : (wave >> 1);
+  const int krow = wave >> 1;   // KSPLIT: the tile row whose k-steps this wave takes
   const int a_lane = (co_t * 32 + l31) * GPITCH + (8 * half) * 2;
-  const int b_lane = l31 * XPITCH + (dy * XC + 8 * half + 4) * 2;     // window = pixels 4 .. 19 past (row, c0 + 8h)
+  const int b_lane = l31 * XPITCH + (dy * XC + 8 * half + (KSPLIT ? 0 : 4)) * 2;   // window = pixels 4 .. 19 past (row, c0 + 8h)
 
-  f32x16 acc[KS];
+  constexpr int NACC = KSPLIT ? CIB : KS;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int j = 0; j < KS; ++j)
+  for (int j = 0; j < NACC; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -175,17 +183,30 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
 
     const unsigned char* xs = lds + (t & 1) * (XBYTES + GBYTES);
     const unsigned char* gs = xs + XBYTES;
-    cm_u32x4 a2[2], wm[2];
+    cm_u32x4 a2[2], wm[2], wk[CIB];
     cm_u32x2 wl[2], wh[2];
 #define CM_READ(ks_, s_)                                                                     \
     {                                                                                        \
       const int r_ = (ks_) / (TW / 16), c0_ = ((ks_) % (TW / 16)) * 16;                      \
       a2[s_] = *(lds_r128)(gs + a_lane + (r_ * TW + c0_) * 2);                               \
       const unsigned char* bp_ = xs + b_lane + (r_ * XC + c0_) * 2;                          \
-      wl[s_] = *(lds_r64)(bp_);                                                              \
-      wm[s_] = *(lds_r128)(bp_ + 8);                                                         \
-      wh[s_] = *(lds_r64)(bp_ + 24);                                                         \
+      if constexpr (KSPLIT) {               /* k = 1: the fragments are the aligned 8 pixels of each cin tile */ \
+        _Pragma("unroll") for (int j = 0; j < CIB; ++j) wk[j] = *(lds_r128)(bp_ + j * 32 * XPITCH); \
+      } else {                                                                               \
+        wl[s_] = *(lds_r64)(bp_);                                                            \
+        wm[s_] = *(lds_r128)(bp_ + 8);                                                       \
+        wh[s_] = *(lds_r64)(bp_ + 24);                                                       \
+      }                                                                                      \
     }
+    if constexpr (KSPLIT) {
+#pragma unroll
+      for (int c = 0; c < TW / 16; ++c) {
+        CM_READ(krow * (TW / 16) + c, 0)
+#pragma unroll
+        for (int j = 0; j < CIB; ++j)
+          acc[j] = E::mfma(*reinterpret_cast<const vec8*>(&a2[0]), *reinterpret_cast<const vec8*>(&wk[j]), acc[j]);
+      }
+    } else {
     CM_READ(0, 0)
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
@@ -208,12 +229,35 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
         acc[dx] = E::mfma(av, *reinterpret_cast<const vec8*>(&f), acc[dx]);
       }
     }
+    }
 #undef CM_READ
     if (has_next) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
   float* __restrict__ wsp = p.ws + (long)split * (KS * KS) * p.cout * p.cin;
+  if constexpr (KSPLIT) {
+    // sum the TH row-group partials of each (cout tile, cin tile) in fixed order (deterministic) through LDS
+    float* red = reinterpret_cast<float*>(lds);                  // [krow][co_t][16][64] floats = 8 KB per row group
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((krow * 2 + co_t) * 16 + r) * 64 + lane] = acc[j][r];
+      __syncthreads();
+      if (krow == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = red[((0 * 2 + co_t) * 16 + r) * 64 + lane];
+#pragma unroll
+          for (int g = 1; g < TH; ++g) v += red[((g * 2 + co_t) * 16 + r) * 64 + lane];
+          const int co = cob * 64 + co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          wsp[(long)co * p.cin + (cib * CIB + j) * 32 + l31] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx) {
     const int tap = dy * KS + dx;
@@ -227,10 +271,11 @@ __global__ __launch_bounds__(2 * KS * 64, 3) void conv_wgrad_cm16_kernel(const W
 }
 
 bool conv_wgrad_cm16_supported(const codon_conv_desc* d, const void* x, const void* gy) {
-  if (!(d->ksize == 3 || d->ksize == 5)) return false;
+  if (!(d->ksize == 1 || d->ksize == 3 || d->ksize == 5)) return false;
+  if (d->ksize == 1 && d->cin % (32 * CM_CIB1) != 0) return false;
   if (d->width % 8 != 0) return false;
   const long HW = (long)d->height * d->width;
-  if (HW * 2 * 64 >= 0xFFFFFFF0L) return false;                       // 32-bit chunk offsets: 64 planes of a slice
+  if (HW * 2 * 128 >= 0xFFFFFFF0L) return false;                      // 32-bit chunk offsets: up to 128 planes of a slice
   // every chunk address = slice start + 2 * (plane * HW + row * W + 8 * k): 16-byte aligned iff the slice start is
   // (W % 8 == 0 makes HW % 8 == 0)
   const uintptr_t xa = reinterpret_cast<uintptr_t>(x) + 2 * (uintptr_t)(d->x_coff * HW);
@@ -248,14 +293,18 @@ int launch_wgrad_cm16(const codon_conv_desc* d, const void* x, const void* gy, f
   p.x_base = d->x_coff * HW; p.g_base = d->y_coff * HW;
   p.tiles_x = tiles_x; p.band_tiles_y = band_rows / CM_TH;   // band_rows: a multiple of 8
   p.nbands = nbands; p.nsplit = nsplit;
-  const dim3 grid(nchan_blocks, nsplit);
+  dim3 grid(nchan_blocks, nsplit);
+  if (d->ksize == 1) grid.x = (d->cout / 64) * (d->cin / (32 * CM_CIB1));
   const bool f16 = d->dtype == CODON_F16;
   if (d->ksize == 5) {
     if (f16) hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmF16, 5>), grid, dim3(640), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmBf16, 5>), grid, dim3(640), 0, stream, p);
-  } else {
+  } else if (d->ksize == 3) {
     if (f16) hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmF16, 3>), grid, dim3(384), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmBf16, 3>), grid, dim3(384), 0, stream, p);
+  } else {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmF16, 1>), grid, dim3(2 * CM_TH * 64), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_cm16_kernel<CmBf16, 1>), grid, dim3(2 * CM_TH * 64), 0, stream, p);
   }
   return check_launch("conv_wgrad_cm16_kernel");
 }
