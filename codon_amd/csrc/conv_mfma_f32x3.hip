@@ -71,8 +71,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
   constexpr int WS1 = KS * NCB * COUTB;      // 16-byte elements per weight part of a stage
   constexpr int WS = 2 * WS1;                // hi + lo
   constexpr int NST = NCHUNK * KS;
-  constexpr int XW = (CK / 2) * XR * XQ;     // channel-pair words per x tile
-  constexpr int XE = (XW + NT - 1) / NT;
+  constexpr int XE = (XS + NT - 1) / NT;     // 16-byte elements per thread per chunk
   constexpr int WE = (WS + NT - 1) / NT;
 
   __shared__ uint4 lds[2 * XS + 2 * WS];
@@ -101,46 +100,46 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32x3_kernel(const ConvS
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (int)((unsigned)CIN * 4u * (unsigned)HW), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (int)(NST * WS * 16), 0x00020000);
 
+  // staging unit = one 16-byte element of the channel-blocked images = 8 channels of one pixel: element e = tid + NT k
+  // = (cb, r, q) has LDS index e in both images, so a round is two conflict-free ds_write_b128 per thread (the
+  // per-channel-pair version wrote 16-byte-strided words: 8-way bank conflicts, twice).  Out-of-image / padding
+  // elements use an out-of-range buffer offset: the loads return 0.
   unsigned xoff[XE];
-  int xdst[XE];
-  unsigned xmask = 0;
 #pragma unroll
   for (int k = 0; k < XE; ++k) {
     const int e = tid + k * NT;
-    const int cp = e / (XR * XQ);
-    const int rem = e - cp * (XR * XQ);
+    const int cb = e / (XR * XQ);
+    const int rem = e - cb * (XR * XQ);
     const int r = rem / XQ, q = rem - r * XQ;
     const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
-    const bool ok = (e < XW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    xoff[k] = ok ? 4u * (unsigned)((2 * cp) * HW + (long)gy * W + gx) : 0u;   // byte offset in the image slice
-    xmask |= ok ? (1u << k) : 0u;
-    xdst[k] = (((cp >> 2) * XR + r) * XQ + q) * 4 + (cp & 3);                 // 32-bit word inside an image
+    const bool ok = (e < XS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    xoff[k] = ok ? 4u * (unsigned)((8 * cb) * HW + (long)gy * W + gx) : 0xFFFFFFF0u;   // byte offset in the image slice
   }
 
-  float x0[XE], x1[XE];  // the two channels of a word, raw fp32, until the split at store time
+  float xv[XE][8];  // the 8 channels of an element, raw fp32, until the split at store time
   uint4 wr[WE];
 
 #define LOAD_X(chunk_)                                                                   \
   {                                                                                      \
     const unsigned so_ = (unsigned)(chunk_) * (unsigned)(CK * 4) * (unsigned)HW;         \
-    const unsigned so1_ = so_ + 4u * (unsigned)HW;                                       \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) {                                     \
-      x0[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[k], so_, 0));  \
-      x1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[k], so1_, 0)); \
-    }                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < XE; ++k)                                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                      \
+        xv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[k], so_ + (unsigned)j * 4u * (unsigned)HW, 0)); \
   }
 #define STORE_X()                                                                        \
   {                                                                                      \
-    unsigned* dh_ = reinterpret_cast<unsigned*>(xh);                                     \
-    unsigned* dl_ = reinterpret_cast<unsigned*>(xl);                                     \
     _Pragma("unroll") for (int k = 0; k < XE; ++k)                                       \
-        if (XW % NT == 0 || tid + k * NT < XW) {                                         \
-          const bool m_ = (xmask >> k) & 1u;                                             \
-          const float a_ = m_ ? x0[k] : 0.f, b_ = m_ ? x1[k] : 0.f;                      \
-          const u16 ah_ = f2h_bits(a_), bh_ = f2h_bits(b_);                              \
-          const u16 al_ = f2h_bits(a_ - h2f_bits(ah_)), bl_ = f2h_bits(b_ - h2f_bits(bh_)); \
-          dh_[xdst[k]] = (unsigned)ah_ | ((unsigned)bh_ << 16);                          \
-          dl_[xdst[k]] = (unsigned)al_ | ((unsigned)bl_ << 16);                          \
+        if (XS % NT == 0 || tid + k * NT < XS) {                                         \
+          unsigned hw_[4], lw_[4];                                                       \
+          _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                \
+            const float a_ = xv[k][2 * w], b_ = xv[k][2 * w + 1];                        \
+            const u16 ah_ = f2h_bits(a_), bh_ = f2h_bits(b_);                            \
+            const u16 al_ = f2h_bits(a_ - h2f_bits(ah_)), bl_ = f2h_bits(b_ - h2f_bits(bh_)); \
+            hw_[w] = (unsigned)ah_ | ((unsigned)bh_ << 16);                              \
+            lw_[w] = (unsigned)al_ | ((unsigned)bl_ << 16);                              \
+          }                                                                              \
+          xh[tid + k * NT] = make_uint4(hw_[0], hw_[1], hw_[2], hw_[3]);                 \
+          xl[tid + k * NT] = make_uint4(lw_[0], lw_[1], lw_[2], lw_[3]);                 \
         }                                                                                \
   }
 #define LOAD_W(stage_)                                                                   \
