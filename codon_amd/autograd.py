@@ -44,15 +44,19 @@ class _CodonFn(torch.autograd.Function):
             xf, yf = x.float().contiguous(), y.float().contiguous()
             out = model._forward_impl(xf, yf, save)
         ctx.model, ctx.saved, ctx.x, ctx.y = model, save, xf, yf
+        ctx.in_dtype = x.dtype
         return out if x.dtype == torch.float32 else out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, g_out):
         model, S, x, y = ctx.model, ctx.saved, ctx.x, ctx.y
         with torch.no_grad():
-            grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous())
+            need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous(), input_grads=need)
         ctx.saved = None
-        return (None, None, None) + tuple(grads[n].to(p.dtype) for n, p in used_parameters(model))
+        gx = grads["__input"].to(ctx.in_dtype) if need[0] else None
+        gyy = grads["__input_c"].to(ctx.in_dtype) if need[1] else None
+        return (None, gx, gyy) + tuple(grads[n].to(p.dtype) for n, p in used_parameters(model))
 
 
 def codon_apply(model, x, y):
@@ -60,7 +64,7 @@ def codon_apply(model, x, y):
     return _CodonFn.apply(model, x, y, *params)
 
 
-def _backward_impl(model, S, x, y, gy, debug=None):
+def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     B, _, H, W = x.shape
     dev = x.device
     adt = model._act_dtype()                       # activation-gradient dtype follows the activations
@@ -173,4 +177,11 @@ def _backward_impl(model, S, x, y, gy, debug=None):
         ops.conv2d(Slice(g_in2, off, 64), Pd(nm_ci), Slice(g_s), 3, relu_mask=Slice(st))
         G[nm_in + ".weight"] = torch.empty_like(getattr(model, nm_in).weight, dtype=torch.float32)
         ops.conv1ch_wgrad(Slice(g_s), img, G[nm_in + ".weight"], flip=False)
+        # dL/d(input image) when asked for: the 64 -> 1 dgrad of the stem is the head stencil with the flipped,
+        # transposed kernel; x also feeds the final residual add (CODON_x4.py:67,131): + gy
+        if input_grads[off // 64]:
+            wt = f32(getattr(model, nm_in).weight).flip(2, 3).permute(1, 0, 2, 3).contiguous()   # (1,64,3,3)
+            g_img = torch.empty_like(gy)
+            ops.head(Slice(g_s), wt, gy if off == 0 else torch.zeros_like(gy), g_img)
+            G["__input_c" if off else "__input"] = g_img
     return G

@@ -245,3 +245,29 @@ def test_bf16_training_gradients_vs_fp32_oracle():
             num += float((p.grad.cpu().double() - gref[k].double()).pow(2).sum())
             den += float(gref[k].double().pow(2).sum())
     assert (num / den) ** 0.5 <= 5e-2
+
+
+def test_input_gradients_match_oracle_autograd():
+    """dL/dx and dL/dy (the reference's autograd provides them when the inputs require grad): the stems' 64 -> 1 dgrad
+    through the head stencil, plus the identity path of the final residual add for x."""
+    sd = orc.he_state("x4", seed=33)
+    g = np.random.default_rng(9)
+    B, H, W = 2, 21, 38
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    up = torch.from_numpy(g.standard_normal(size=(B, 1, H, W)).astype(np.float32)) / (B * H * W)
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    out_ref = orc.forward(sd, xr, yr)
+    out_ref.backward(up)
+    m = _model("x4", sd)
+    xd, yd = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    out = m(xd, yd)
+    flips = _relu_mask_flips(out.grad_fn.saved, sd, x, y)
+    out.backward(up.cuda())
+    tol = GRAD_TOL if flips == 0 else 5e-2
+    assert rel_rmse(xd.grad.cpu(), xr.grad) <= tol, flips
+    assert rel_rmse(yd.grad.cpu(), yr.grad) <= tol, flips
+    # only one input asks: the other stays None
+    xd2 = x.cuda().requires_grad_(True)
+    m(xd2, y.cuda()).backward(up.cuda())
+    assert rel_rmse(xd2.grad.cpu(), xr.grad) <= tol
