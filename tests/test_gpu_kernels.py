@@ -290,7 +290,7 @@ def test_bf16_elementwise_kernels():
 
 
 @pytest.mark.parametrize("k,cin,cout", WGRAD_CASES)
-@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70), (1, 130, 40)])
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70), (1, 130, 40), (3, 13, 48), (2, 40, 8)])
 def test_conv2d_wgrad_bf16_vs_autograd(k, cin, cout, shape):
     from codon_amd import ops
     from codon_amd.ops import Slice
@@ -308,11 +308,12 @@ def test_conv2d_wgrad_bf16_vs_autograd(k, cin, cout, shape):
     assert rel_rmse(dw.cpu(), 2 * w.grad) < 1e-5
 
 
-def test_conv2d_wgrad_bf16_slices():
+@pytest.mark.parametrize("W", [37, 40])       # 37: pixel-major fallback kernel; 40: channel-major kernel (W % 8 == 0)
+def test_conv2d_wgrad_bf16_slices(W):
     from codon_amd import ops
     from codon_amd.ops import Slice
     dev = _dev()
-    B, H, W = 2, 21, 37
+    B, H = 2, 21
     xb = _rand((B, 128, H, W), 1).bfloat16()
     gb = _rand((B, 128, H, W), 2).bfloat16()
     w = torch.zeros((64, 64, 5, 5), requires_grad=True)
