@@ -101,7 +101,7 @@ def cpu_baseline(H, W):
 
 
 def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
-    """One step = zero_grad, forward, per-image-mean L1 loss, backward (HIP dgrad/wgrad/CAC kernels), ONE
+    """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP dgrad/wgrad/CAC kernels), ONE
     all-reduce of the flat gradient buffer (RCCL when world > 1), Adam step.  Nothing is skipped."""
     from codon_amd.dist import GradSync
     B, H, W = a.batch, a.height, a.width
@@ -112,10 +112,13 @@ def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
     tgt = torch.rand((B, 1, H, W), generator=g, device=dev)
 
+    from codon_amd.metrics import L1SSIMLoss
+    crit = L1SSIMLoss(1.0, 1.0)          # BASELINE.json configs[2]: L1 + SSIM (HIP forward + backward)
+
     def step():
         gs.zero_grad()
         out = model(x, y)
-        loss = (out - tgt).abs().mean()
+        loss = crit(out.float(), tgt)
         loss.backward()
         gs.all_reduce_grads()
         opt.step()
@@ -140,7 +143,7 @@ def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
         res = {"metric": "iters/sec (fwd+bwd)", "value": a.steps / dt, "unit": "it/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"CODON x{a.scale} forward+backward (L1 loss, Adam), batch {B}/GPU at {H}x{W}, "
+               "config": {"workload": f"CODON x{a.scale} forward+backward (L1 + SSIM loss, Adam), batch {B}/GPU at {H}x{W}, "
                                       f"{a.dtype}" + (" activations/gradients, fp32 accumulate + master weights "
                                                       "(BASELINE.json configs[2] per-GPU shape)" if a.dtype == "bf16" else ""),
                           "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
@@ -174,7 +177,7 @@ def main():
                     help="fp32 only. exact (default): fp32 MFMA. f16x3: OPT-IN split-precision convs (3 f16 MFMAs per "
                          "product, fp32 accumulate, ~2^-22 per product) -- reported with its own dtype label")
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
-                    help="fwd: BASELINE metric (maps/s); train: fwd + L1 loss + bwd + grad all-reduce + Adam step (iters/s)")
+                    help="fwd: BASELINE metric (maps/s); train: fwd + L1+SSIM loss + bwd + grad all-reduce + Adam step (iters/s)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
