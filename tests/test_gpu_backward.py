@@ -271,3 +271,33 @@ def test_input_gradients_match_oracle_autograd():
     xd2 = x.cuda().requires_grad_(True)
     m(xd2, y.cuda()).backward(up.cuda())
     assert rel_rmse(xd2.grad.cpu(), xr.grad) <= tol
+
+
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16])
+def test_training_steps_reduce_the_loss(dtype):
+    """End-to-end sanity of the whole training path (forward, L1+SSIM loss kernels, backward kernels, GradSync flat
+    buffer, Adam): a few steps on one fixed batch must bring the loss down substantially."""
+    from codon_amd import CODONNet
+    from codon_amd.dist import GradSync
+    from codon_amd.metrics import L1SSIMLoss
+    torch.manual_seed(3)
+    m = CODONNet().cuda().train()
+    if dtype is not None:
+        m.set_compute_dtype(dtype)
+    gs = GradSync(m)
+    opt = torch.optim.Adam(gs.params, lr=2e-4)
+    crit = L1SSIMLoss(1.0, 1.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((2, 1, 48, 64), generator=g, device="cuda")
+    y = torch.rand((2, 1, 48, 64), generator=g, device="cuda")
+    tgt = (0.5 * x + 0.25).clamp(0, 1)
+    losses = []
+    for _ in range(25):
+        gs.zero_grad()
+        loss = crit(m(x, y).float(), tgt)
+        loss.backward()
+        gs.all_reduce_grads()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.5 * losses[0], losses
