@@ -76,8 +76,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(const Wgrad16Pa
   const int split = blockIdx.y;
   const int b = split / p.nbands, band = split % p.nbands;
   const int tiles_y = (H + TH - 1) / TH;
-  const int ty_begin = band * p.band_tiles_y;
-  const int ty_end = min(ty_begin + p.band_tiles_y, tiles_y);
+  const int ty_begin = (int)((long)band * tiles_y / p.nbands);          // tile rows spread evenly over the bands
+  const int ty_end = (int)((long)(band + 1) * tiles_y / p.nbands);
   const int ntile = (ty_end - ty_begin) * p.tiles_x;
 
   const u16* __restrict__ xg = p.x + b * p.x_img + p.x_base + (long)cib * 32 * HW;
@@ -306,6 +306,11 @@ bool conv_wgrad_cm16_supported(const codon_conv_desc* d, const void* x, const vo
 int launch_wgrad_cm16(const codon_conv_desc* d, const void* x, const void* gy, float* workspace, int tiles_x,
                       int band_tiles_y, int nbands, int nsplit, int nchan_blocks, hipStream_t stream);
 
+#ifndef CODON_WGRAD16_TARGET
+#define CODON_WGRAD16_TARGET 512
+#endif
+constexpr int WGRAD16_TARGET_BLOCKS = CODON_WGRAD16_TARGET;   // workgroups per launch the band split aims for
+
 struct Wgrad16Plan {
   int nbands, band_tiles_y, nsplit, nchan_blocks;
 };
@@ -314,16 +319,15 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   const int k = d->ksize, ci = d->cin, co = d->cout;
   if (!((k == 1 || k == 3 || k == 5) && ci % 32 == 0 && co % 64 == 0)) return false;
   pl->nchan_blocks = (co / 64) * (ci / 32);
-  // bands are whole multiples of 8 image rows (both kernels' tile heights, 4 and 8, divide them)
-  const int tiles_y8 = (d->height + 7) / 8;
+  // every band gets floor or ceil of tiles_y / nbands tile rows (both kernels use 4-row tiles)
+  const int tiles_y = (d->height + 3) / 4;
   // k = 1 through conv_wgrad_cm16.hip covers 128 cin per workgroup: size the split for that (smaller) grid
   const int nb = (k == 1 && ci % 128 == 0) ? (co / 64) * (ci / 128) : pl->nchan_blocks;
-  int want = (512 + nb * d->batch - 1) / (nb * d->batch);   // ~2 workgroups per CU
+  int want = (WGRAD16_TARGET_BLOCKS + nb * d->batch - 1) / (nb * d->batch);
   if (want < 1) want = 1;
-  if (want > tiles_y8) want = tiles_y8;
-  const int band8 = (tiles_y8 + want - 1) / want;
-  pl->nbands = (tiles_y8 + band8 - 1) / band8;
-  pl->band_tiles_y = 2 * band8;                       // in 4-row tiles
+  if (want > tiles_y) want = tiles_y;
+  pl->nbands = want;
+  pl->band_tiles_y = (tiles_y + want - 1) / want;     // upper bound (informational)
   pl->nsplit = d->batch * pl->nbands;
   return true;
 }

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(KS == 1 ? 2 * CM_TH * 64 : 2 * KS * 64, 3) void con
   const int split = blockIdx.y;
   const int b = split / p.nbands, band = split % p.nbands;
   const int tiles_y = (H + TH - 1) / TH;
-  const int ty_begin = band * p.band_tiles_y;
-  const int ty_end = min(ty_begin + p.band_tiles_y, tiles_y);
+  const int ty_begin = (int)((long)band * tiles_y / p.nbands);          // tile rows spread evenly over the bands
+  const int ty_end = (int)((long)(band + 1) * tiles_y / p.nbands);
   const int ntile = (ty_end - ty_begin) * p.tiles_x;
 
   const unsigned short* const xg = p.x + b * p.x_img + p.x_base + (long)cib * 32 * CIB * HW;
