@@ -35,6 +35,8 @@ size_t conv_wgrad_bf16_workspace_bytes(const codon_conv_desc*);
 int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, float*, size_t, int, hipStream_t);
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
 int pack_chain1x1_f32(const float*, float*, hipStream_t);
+int conv2d_gated_fwd_f32(const codon_conv_desc*, const float*, const codon_tensor*, const float*, const float*, const float*,
+                         float*, hipStream_t);
 int pack_chain1x1_16(const float*, void*, int, hipStream_t);
 int pack_chain1x1_f32x3(const float*, void*, hipStream_t);
 int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const void*, const codon_tensor*,
@@ -188,6 +190,25 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
     return conv_chain1x1_fwd_f32x3(d, (const float*)x, w_packed, (float*)y, w_chain, out, residual, (hipStream_t)stream);
   return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out,
                                residual, (hipStream_t)stream);
+}
+
+int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                           const float* sp, const void* w_packed, void* y, codon_stream_t stream) {
+  CODON_REQUIRE(d && pre && inputs && inputs->data && ch && sp && w_packed && y, CODON_ERR_BAD_ARG,
+                "conv2d_gated_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_gated_fwd: bad shape %dx%dx%d",
+                d->batch, d->height, d->width);
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->x_coff % 64 == 0, CODON_ERR_BAD_ARG,
+                "conv2d_gated_fwd: input slice [%d,%d) of %d channels (must start at a multiple of 64)", d->x_coff,
+                d->x_coff + d->cin, d->x_ctotal);
+  CODON_REQUIRE(inputs->coff >= 0 && inputs->coff + d->cin <= inputs->ctotal, CODON_ERR_BAD_ARG,
+                "conv2d_gated_fwd: `inputs` slice outside its buffer");
+  CODON_REQUIRE(d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal, CODON_ERR_BAD_ARG,
+                "conv2d_gated_fwd: output slice outside its buffer");
+  CODON_REQUIRE((d->flags & ~CODON_CONV_RELU) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: only the RELU flag applies");
+  CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: dtype %d (fp32 only)", d->dtype);
+  return conv2d_gated_fwd_f32(d, (const float*)pre, inputs, ch, sp, (const float*)w_packed, (float*)y, (hipStream_t)stream);
 }
 
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {

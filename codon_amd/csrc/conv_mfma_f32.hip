@@ -43,6 +43,12 @@ struct ConvParams {
 #ifdef CODON_TIMING
   long long* dbg;
 #endif
+  // GATE only: the conv input is formed while staging, x = pre * (ch * sp) + in  (the CAC gate-apply of the
+  // producing block, CODON_x4.py:89-91,117-118): p.x = pre, same slice of `in2`, ch (B,64), sp (B,1,H,W)
+  const float* in2;
+  const float* ch;
+  const float* sp;
+  long in_img, in_base;
   // FUSE only: the chained 1x1 (128 -> 64) applied to the tile while it is still in the accumulators
   const float* w2;  // [t2][t][lane][16]: W1[t2*32 + (lane&31)][t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
   float* y2;
@@ -91,7 +97,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // residual modes of the epilogue (compile-time variants: one VALU op per element each)
 enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams p) {
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = 4 * PSEG;
@@ -157,6 +163,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
       if (r >= XR) { r -= XR; c += 1; }
     }
   }
+  // GATE: position-major staging -- a thread owns PJ pixel positions of the halo tile and walks the chunk's CK
+  // channels over them (plane term = SGPR offset), so the per-pixel gate sp sits in PJ registers for the whole tile
+  // and the per-channel gate ch is a scalar per chunk:  x = fma(pre, ch * sp, in)  exactly as cac_apply_kernel.
+  constexpr int NPOS = XR * XQ, PJ = (NPOS + 255) / 256;
+  unsigned poff[GATE ? PJ : 1];
+  float spv[GATE ? PJ : 1];
+  const float* const inbase = GATE ? p.in2 + (long)b * p.in_img + p.in_base : nullptr;
+  const float* const chp = GATE ? p.ch + (long)b * 64 : nullptr;
+  if constexpr (GATE) {
+    const __amdgpu_buffer_rsrc_t sprsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.sp + (long)b * HWl), 0, (int)HW4, BUF_FLAGS);
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      const int pos = tid + j * 256;
+      const int r = pos / XQ, q = pos - r * XQ;
+      const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+      const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      poff[j] = ok ? 4u * (unsigned)(gy * W + gx) : BUF_OOB;
+      spv[j] = buf_ld(sprsrc, poff[j], 0u);
+    }
+  }
+  float xg_[GATE ? CK : 1][GATE ? PJ : 1], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
+
   // weight stage: float4 element tid + 256 k of the stage; the padding round is out of range
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (W4 % 256 == 0 || tid + (WE - 1) * 256 < W4) ? wvo : BUF_OOB;
@@ -168,12 +197,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 #define LOAD_X(chunk_)                                                             \
   {                                                                                \
     const __amdgpu_buffer_rsrc_t xr_ = planes(xbase, (chunk_) * CK, CK);           \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xr_, xoff[k], 0u); \
+    if constexpr (GATE) {                                                          \
+      const __amdgpu_buffer_rsrc_t ir_ = planes(inbase, (chunk_) * CK, CK);        \
+      _Pragma("unroll") for (int c = 0; c < CK; ++c) {                             \
+        chs[c] = chp[(((chunk_) * CK) & 63) + c];      /* wave-uniform: scalar load */ \
+        _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                           \
+          xg_[c][j] = buf_ld(xr_, poff[j], (unsigned)c * HW4);                     \
+          xi_[c][j] = buf_ld(ir_, poff[j], (unsigned)c * HW4);                     \
+        }                                                                          \
+      }                                                                            \
+    } else {                                                                       \
+      _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xr_, xoff[k], 0u); \
+    }                                                                              \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \
     float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
-    _Pragma("unroll") for (int k = 0; k < XE; ++k) dst_[k * 256] = xr[k];          \
+    if constexpr (GATE) {                                                          \
+      _Pragma("unroll") for (int j = 0; j < PJ; ++j)                               \
+        if (NPOS % 256 == 0 || tid + j * 256 < NPOS) {                             \
+          _Pragma("unroll") for (int c = 0; c < CK; ++c)                           \
+            dst_[c * NPOS + j * 256] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
+        }                                                                          \
+    } else {                                                                       \
+      _Pragma("unroll") for (int k = 0; k < XE; ++k) dst_[k * 256] = xr[k];        \
+    }                                                                              \
   }
 #define LOAD_W(stage_)                                                             \
   {                                                                                \
@@ -453,11 +501,53 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   p.dbg = codon_dbg_ptr();
 #endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
+  p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel");
 }
 
 int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
+
+template <int KS, int CIN, int COUT>
+static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
+                        const float* sp, const float* w, float* y, hipStream_t stream) {
+  constexpr int TH = 8;
+  ConvParams p;
+  p.x = pre; p.w = w; p.y = y; p.res = nullptr;
+  p.H = d->height; p.W = d->width;
+  const long HW = (long)d->height * d->width;
+  p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = 0;
+  p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = 0;
+  p.in2 = (const float*)in2->data; p.in_img = in2->ctotal * HW; p.in_base = in2->coff * HW;
+  p.ch = ch; p.sp = sp;
+  p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + TH - 1) / TH;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: grid too large (%ld blocks)", nblk);
+  CODON_REQUIRE(HW * 4 * 32 < (long)BUF_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_gated_fwd: %dx%d image: 32 channel planes exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  p.nblk = (int)nblk;
+  p.flags = d->flags;
+#ifdef CODON_TIMING
+  p.dbg = codon_dbg_ptr();
+#endif
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, 2, false, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_mfma_f32_kernel<gated>");
+}
+
+int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
+                         const float* sp, const float* w, float* y, hipStream_t stream) {
+  const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
+  switch (key) {
+    case 5064064: return launch_gated<5, 64, 64>(d, pre, in2, ch, sp, w, y, stream);
+    case 3064064: return launch_gated<3, 64, 64>(d, pre, in2, ch, sp, w, y, stream);
+    case 3128064: return launch_gated<3, 128, 64>(d, pre, in2, ch, sp, w, y, stream);
+    default:
+      set_error("conv2d_gated_fwd: no f32 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      return CODON_ERR_UNSUPPORTED;
+  }
+}
 
 // d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1
 int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* w_chain,
@@ -471,6 +561,7 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   const long HW = (long)d->height * d->width;
   p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = res ? res->ctotal * HW : 0;
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = res ? res->coff * HW : 0;
+  p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.w2 = w_chain; p.y2 = (float*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;

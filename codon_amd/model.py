@@ -216,6 +216,17 @@ class _CODONBase(nn.Module):
             ops.conv_chain1x1(xs, P(name5), P(name1, chain_mode), ys, mid=mid if keep else None, residual=residual,
                               f16x3=split5)
 
+        # inference, exact fp32: the gate-apply `out*ad_CAC + inputs` (:89-91,117-118) is formed inside the staging of
+        # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
+        gated = (not keep) and adt == torch.float32 and not split5
+
+        def gconv(gate, pre_s, in_s, plain_s, name, ys, k):
+            """relu(conv_k(gate-applied input)): `gate` = (ch, sp) of the producing block or None (plain input)."""
+            if gate is not None:
+                ops.conv2d_gated(pre_s, in_s, gate[0], gate[1], P(name), ys, k, relu=True)
+            else:
+                conv(plain_s, name, ys, k, relu=True)
+
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
@@ -232,7 +243,7 @@ class _CODONBase(nn.Module):
 
         nt = ops.cac_stats_tiles(H, W)
         cur = in2                       # (B,128): [depth | colour] block input
-        oc = None
+        oc = prev_gate = None
         stage = r2 = stage_c = r2_c = pre2 = None
         for i in range(5):
             if keep or stage is None:
@@ -245,13 +256,14 @@ class _CODONBase(nn.Module):
             pools = torch.empty((B, 2, 128), dtype=torch.float32, device=dev) if keep else None
             out, out_c = Slice(cur, 0, 64), Slice(cur, 64, 64)
             pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
+            gate = prev_gate if (gated and i > 0) else None      # (ch, sp) of block i-1: its apply runs in our staging
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
-            conv(out, "conv1", Slice(stage, 0, 64), 3, relu=True)
-            conv(out, "conv2", Slice(stage, 64, 64), 5, relu=True)
+            gconv(gate, pre, inputs, out, "conv1", Slice(stage, 0, 64), 3)
+            gconv(gate, pre, inputs, out, "conv2", Slice(stage, 64, 64), 5)
             conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre)   # :81,84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
-            conv(out_c, "conv4", Slice(stage_c, 0, 64), 5, relu=True)
-            conv(out_c, "conv5", Slice(stage_c, 64, 64), 3, relu=True)
+            gconv(gate, pre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5)
+            gconv(gate, pre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3)
             conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c)   # :82,83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
@@ -259,17 +271,24 @@ class _CODONBase(nn.Module):
             ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
                          f32(ac.mlp[3].bias), ch, pools)
             ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
-            if keep or oc is None:
-                oc = new(128)           # [out | out_c]: also conv7's cat(out, out_c) input  :119
-            ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
+            if gated:
+                prev_gate = (ch, sp)    # consumed by the next block's convs / conv7
+            else:
+                if keep or oc is None:
+                    oc = new(128)       # [out | out_c]: also conv7's cat(out, out_c) input  :119
+                ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
             if keep:
                 save[f"blk{i}"] = dict(x=cur, stage=stage, r2=r2, stage_c=stage_c, r2_c=r2_c, pre2=pre2,
                                        pooled=pooled, pools=pools, ch=ch, sp=sp)
-            cur = oc
+            if not gated:
+                cur = oc
 
         # fusion trunk                                                               :119-128
         fuse = new(64)
-        conv(Slice(cur), "conv7", Slice(fuse), 3, relu=True)
+        if gated:
+            ops.conv2d_gated(Slice(pre2), Slice(in2), prev_gate[0], prev_gate[1], P("conv7"), Slice(fuse), 3, relu=True)
+        else:
+            conv(Slice(cur), "conv7", Slice(fuse), 3, relu=True)
         if keep:
             save["oc"], save["fuse"] = cur, fuse
         f = fuse

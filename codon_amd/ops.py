@@ -148,6 +148,23 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
             prof["chained"] = True
 
 
+def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, w_packed: torch.Tensor, y: Slice,
+                 ksize: int, relu: bool = False):
+    """y = conv(pre * (ch * sp) + inputs) [relu]: the CAC gate-apply of the producing block formed while staging."""
+    lib = L.load()
+    dev = _dev(pre.buf, inputs.buf, ch, sp, w_packed, y.buf)
+    B, _, H, W = pre.buf.shape
+    assert inputs.c == pre.c and inputs.buf.shape == pre.buf.shape[:1] + inputs.buf.shape[1:2] + pre.buf.shape[2:]
+    assert ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64) and ch.is_contiguous()
+    assert sp.dtype == torch.float32 and tuple(sp.shape) == (B, 1, H, W) and sp.is_contiguous()
+    d = L.ConvDesc(B, H, W, pre.c, y.c, ksize, pre.ctotal, pre.coff, y.ctotal, y.coff, 0, 0,
+                   L.CONV_RELU if relu else 0, _dt(pre.buf))
+    it = inputs.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_conv2d_gated_fwd(C.byref(d), _ptr(pre.buf), C.byref(it), _ptr(ch), _ptr(sp), _ptr(w_packed),
+                                           _ptr(y.buf), _stream(dev)), "conv2d_gated_fwd")
+
+
 def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: bool = False):
     """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy."""
     lib = L.load()

@@ -106,6 +106,17 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
                             const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
                             codon_stream_t stream);
 
+/* A conv whose input is the CAC gate-apply of the producing block, formed while the input tile is staged instead of
+ * being written to HBM and read back (inference):   x = pre * (ch * sp) + inputs ,  y = conv(x) [ReLU]
+ *   out*ad_CAC + inputs  /  out_c*ad_CAC + inputs_c  feeding conv1, conv2 / conv4, conv5 / conv7
+ *   /root/reference/CODON_X4/CODON_x4.py:89-91,117-120,75-78.
+ * d->x_* describe `pre` (channels of the (B,128,H,W) [pre | pre_c] buffer); `inputs` = the same channels of
+ * [inputs | inputs_c]; ch: (B,64) fp32 channel gate (channel c of the 128 uses ch[c & 63]); sp: (B,1,H,W) fp32 spatial
+ * gate.  flags: CODON_CONV_RELU only.  Same arithmetic as codon_cac_apply_fwd followed by codon_conv2d_fwd, bit for
+ * bit.  fp32, (k, cin, cout) in {(5,64,64), (3,64,64), (3,128,64)}. */
+int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                           const float* sp, const void* w_packed, void* y, codon_stream_t stream);
+
 /* dL/dw (cout, cin, k, k) fp32 = sum over b,h,w of gy[b,co,h,w] * x[b,ci,h+dy-p,w+dx-p]: what autograd
  * computes for the nn.Conv2d weights (the reference has no explicit backward).
  * d describes the FORWARD conv: x = its input (x_* fields), gy = gradient of its output (y_* fields

@@ -122,3 +122,33 @@ def test_chain1x1_rejects_bad_arguments():
         ops.conv_chain1x1(Slice(x), w, w, Slice(torch.zeros((1, 64, 4, 4), device=dev)))     # cin must be 128
     with pytest.raises(RuntimeError):
         ops.packed_weight(torch.zeros((64, 64, 1, 1), device=dev), L.PACK_CHAIN1X1)           # (64,128,1,1) only
+
+
+@pytest.mark.parametrize("k,cin", [(5, 64), (3, 64), (3, 128)])
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 33, 70), (1, 1, 1), (1, 5, 3), (3, 16, 64)])
+def test_gated_conv_equals_apply_then_conv(shape, k, cin):
+    """codon_conv2d_gated_fwd (the CAC gate-apply formed in the conv's staging) is bit-identical to
+    codon_cac_apply_fwd followed by codon_conv2d_fwd, and equals torch within the fp32 kernel bar."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    coff = 0 if cin == 128 else 64                                   # the colour-stream slice when cin = 64
+    pre2, in2 = _rand((B, 128, H, W), 31), _rand((B, 128, H, W), 32)
+    ch = torch.sigmoid(_rand((B, 64), 33))
+    sp = torch.sigmoid(_rand((B, 1, H, W), 34))
+    w = _rand((64, cin, k, k), 35, scale=(2.0 / (k * k * 64)) ** 0.5)
+    pd, idv, chd, spd = pre2.to(dev), in2.to(dev), ch.to(dev), sp.to(dev)
+    wp = ops.packed_weight(w.to(dev))
+    y = torch.full((B, 64, H, W), float("nan"), device=dev)
+    ops.conv2d_gated(Slice(pd, coff, cin), Slice(idv, coff, cin), chd, spd, wp, Slice(y), k, relu=True)
+    oc = torch.empty((B, 128, H, W), device=dev)
+    ops.cac_apply(Slice(pd, 0, 64), Slice(pd, 64, 64), chd, spd, Slice(idv, 0, 64), Slice(idv, 64, 64),
+                  Slice(oc, 0, 64), Slice(oc, 64, 64))
+    y2 = torch.empty_like(y)
+    ops.conv2d(Slice(oc, coff, cin), wp, Slice(y2), k, relu=True)
+    assert torch.equal(y, y2)
+    g = ch[:, :, None, None] * sp                                     # (B,64,H,W)
+    xin = pre2 * torch.cat([g, g], 1) + in2
+    ref = F.relu(F.conv2d(xin[:, coff:coff + cin], w, None, 1, k // 2))
+    assert rel_rmse(y.cpu(), ref) < 2e-6
