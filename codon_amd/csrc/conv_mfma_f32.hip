@@ -145,35 +145,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 4), BUF_FLAGS);
 
-  // per-thread gather plan for the input halo tile (same for every chunk): element e = tid + 256 k = (c, r, q),
-  // walked incrementally (one division for k = 0, carries afterwards); out-of-image / padding -> BUF_OOB
-  unsigned xoff[XE];
-  {
-    constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
-    int c = tid / (XR * XQ);
-    int rem = tid - c * (XR * XQ);
-    int r = rem / XQ, q = rem - r * XQ;
-#pragma unroll
-    for (int k = 0; k < XE; ++k) {
-      const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
-      const bool ok = c < CK && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      xoff[k] = ok ? (unsigned)c * HW4 + 4u * (unsigned)(gy * W + gx) : BUF_OOB;
-      q += DQ; r += DR; c += DC;
-      if (q >= XQ) { q -= XQ; r += 1; }
-      if (r >= XR) { r -= XR; c += 1; }
-    }
-  }
-  // GATE: position-major staging -- a thread owns PJ pixel positions of the halo tile and walks the chunk's CK
-  // channels over them (plane term = SGPR offset), so the per-pixel gate sp sits in PJ registers for the whole tile
-  // and the per-channel gate ch is a scalar per chunk:  x = fma(pre, ch * sp, in)  exactly as cac_apply_kernel.
+  // Position-major staging: a thread owns PJ pixel positions of the halo tile (same for every chunk) and walks the
+  // chunk's CK channels over them -- the plane term is an SGPR offset, so the whole gather plan is PJ hoisted 32-bit
+  // offsets (out-of-image / padding positions -> BUF_OOB) and costs ~15 VALU per position once per workgroup.
+  // GATE: the per-pixel gate sp sits in PJ registers for the whole tile and the per-channel gate ch is a scalar per
+  // chunk:  x = fma(pre, ch * sp, in)  exactly as cac_apply_kernel computes it.
   constexpr int NPOS = XR * XQ, PJ = (NPOS + 255) / 256;
-  unsigned poff[GATE ? PJ : 1];
+  unsigned poff[PJ];
   float spv[GATE ? PJ : 1];
   const float* const inbase = GATE ? p.in2 + (long)b * p.in_img + p.in_base : nullptr;
   const float* const chp = GATE ? p.ch + (long)b * 64 : nullptr;
-  if constexpr (GATE) {
-    const __amdgpu_buffer_rsrc_t sprsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.sp + (long)b * HWl), 0, (int)HW4, BUF_FLAGS);
+  {
+    __amdgpu_buffer_rsrc_t sprsrc;
+    if constexpr (GATE)
+      sprsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sp + (long)b * HWl), 0, (int)HW4, BUF_FLAGS);
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
       const int pos = tid + j * 256;
@@ -181,47 +166,41 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
       const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
       const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
       poff[j] = ok ? 4u * (unsigned)(gy * W + gx) : BUF_OOB;
-      spv[j] = buf_ld(sprsrc, poff[j], 0u);
+      if constexpr (GATE) spv[j] = buf_ld(sprsrc, poff[j], 0u);
     }
   }
-  float xg_[GATE ? CK : 1][GATE ? PJ : 1], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
+  float xg_[CK][PJ], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
 
   // weight stage: float4 element tid + 256 k of the stage; the padding round is out of range
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (W4 % 256 == 0 || tid + (WE - 1) * 256 < W4) ? wvo : BUF_OOB;
 
-  float xr[XE];
   float4 wr[WE];
 
 // staging steps as macros (not lambdas): keeps xr/wr in registers (no alloca left for scratch)
 #define LOAD_X(chunk_)                                                             \
   {                                                                                \
     const __amdgpu_buffer_rsrc_t xr_ = planes(xbase, (chunk_) * CK, CK);           \
-    if constexpr (GATE) {                                                          \
-      const __amdgpu_buffer_rsrc_t ir_ = planes(inbase, (chunk_) * CK, CK);        \
-      _Pragma("unroll") for (int c = 0; c < CK; ++c) {                             \
-        chs[c] = chp[(((chunk_) * CK) & 63) + c];      /* wave-uniform: scalar load */ \
-        _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                           \
-          xg_[c][j] = buf_ld(xr_, poff[j], (unsigned)c * HW4);                     \
-          xi_[c][j] = buf_ld(ir_, poff[j], (unsigned)c * HW4);                     \
-        }                                                                          \
+    __amdgpu_buffer_rsrc_t ir_;                                                    \
+    if constexpr (GATE) ir_ = planes(inbase, (chunk_) * CK, CK);                   \
+    _Pragma("unroll") for (int c = 0; c < CK; ++c) {                               \
+      if constexpr (GATE) chs[c] = chp[(((chunk_) * CK) & 63) + c];   /* wave-uniform: scalar load */ \
+      _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                             \
+        xg_[c][j] = buf_ld(xr_, poff[j], (unsigned)c * HW4);                       \
+        if constexpr (GATE) xi_[c][j] = buf_ld(ir_, poff[j], (unsigned)c * HW4);   \
       }                                                                            \
-    } else {                                                                       \
-      _Pragma("unroll") for (int k = 0; k < XE; ++k) xr[k] = buf_ld(xr_, xoff[k], 0u); \
     }                                                                              \
   }
 #define STORE_X(buf_)                                                              \
   {                                                                                \
     float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
-    if constexpr (GATE) {                                                          \
-      _Pragma("unroll") for (int j = 0; j < PJ; ++j)                               \
-        if (NPOS % 256 == 0 || tid + j * 256 < NPOS) {                             \
-          _Pragma("unroll") for (int c = 0; c < CK; ++c)                           \
-            dst_[c * NPOS + j * 256] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
+    _Pragma("unroll") for (int j = 0; j < PJ; ++j)                                 \
+      if (NPOS % 256 == 0 || tid + j * 256 < NPOS) {                               \
+        _Pragma("unroll") for (int c = 0; c < CK; ++c) {                           \
+          if constexpr (GATE) dst_[c * NPOS + j * 256] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
+          else dst_[c * NPOS + j * 256] = xg_[c][j];                               \
         }                                                                          \
-    } else {                                                                       \
-      _Pragma("unroll") for (int k = 0; k < XE; ++k) dst_[k * 256] = xr[k];        \
-    }                                                                              \
+      }                                                                            \
   }
 #define LOAD_W(stage_)                                                             \
   {                                                                                \
