@@ -97,10 +97,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // residual modes of the epilogue (compile-time variants: one VALU op per element each)
 enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams p) {
+// NW = waves per workgroup: 4 (8 x 32 tile, two workgroups per CU) or 8 (16 x 32 tile, one 8-wave workgroup per CU:
+// the halo is 20 x 36 / (16 x 32) = 1.41x the tile instead of 1.69x, and the weight stage is staged once per CU).
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvParams p) {
+  constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
-  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int TW = 32, TH = NW * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = ConvCfg<KS, CIN>::CK;
   constexpr int NCHUNK = CIN / CK;
@@ -108,10 +111,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   constexpr int WS = CK * KS * COUT;  // floats per weight stage
   constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * KS;
-  constexpr int XE = (XS + 255) / 256;  // x elements per thread per chunk
   constexpr int W4 = WS / 4;            // float4 per weight stage
-  constexpr int WE = (W4 + 255) / 256;  // float4 per thread per stage
-  constexpr int XSP = XE * 256, WSP = WE * 256 * 4;   // LDS buffers padded to whole rounds: no store predicates
+  constexpr int WE = (W4 + NT - 1) / NT;  // float4 per thread per stage
+  constexpr int XSP = (XS + 3) & ~3, WSP = WE * NT * 4;   // the weight buffer is padded to whole rounds: no store predicates
   static_assert(WS % 4 == 0, "weight stage must be whole float4s");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * XSP + 2 * WSP];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   // offsets (out-of-image / padding positions -> BUF_OOB) and costs ~15 VALU per position once per workgroup.
   // GATE: the per-pixel gate sp sits in PJ registers for the whole tile and the per-channel gate ch is a scalar per
   // chunk:  x = fma(pre, ch * sp, in)  exactly as cac_apply_kernel computes it.
-  constexpr int NPOS = XR * XQ, PJ = (NPOS + 255) / 256;
+  constexpr int NPOS = XR * XQ, PJ = (NPOS + NT - 1) / NT;
   unsigned poff[PJ];
   float spv[GATE ? PJ : 1];
   const float* const inbase = GATE ? p.in2 + (long)b * p.in_img + p.in_base : nullptr;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
       sprsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sp + (long)b * HWl), 0, (int)HW4, BUF_FLAGS);
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
-      const int pos = tid + j * 256;
+      const int pos = tid + j * NT;
       const int r = pos / XQ, q = pos - r * XQ;
       const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
       const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
 
   // weight stage: float4 element tid + 256 k of the stage; the padding round is out of range
   const unsigned wvo = (unsigned)tid * 16u;
-  const unsigned wvo_last = (W4 % 256 == 0 || tid + (WE - 1) * 256 < W4) ? wvo : BUF_OOB;
+  const unsigned wvo_last = (W4 % NT == 0 || tid + (WE - 1) * NT < W4) ? wvo : BUF_OOB;
 
   float4 wr[WE];
 
@@ -195,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   {                                                                                \
     float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
     _Pragma("unroll") for (int j = 0; j < PJ; ++j)                                 \
-      if (NPOS % 256 == 0 || tid + j * 256 < NPOS) {                               \
+      if (NPOS % NT == 0 || tid + j * NT < NPOS) {                                 \
         _Pragma("unroll") for (int c = 0; c < CK; ++c) {                           \
-          if constexpr (GATE) dst_[c * NPOS + j * 256] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
-          else dst_[c * NPOS + j * 256] = xg_[c][j];                               \
+          if constexpr (GATE) dst_[c * NPOS + j * NT] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
+          else dst_[c * NPOS + j * NT] = xg_[c][j];                                \
         }                                                                          \
       }                                                                            \
   }
@@ -206,14 +208,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvParams 
   {                                                                                \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 4);                  \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                               \
-      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * 4096u, 0); \
+      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0); \
       wr[k] = *reinterpret_cast<const float4*>(&v_);                               \
     }                                                                              \
   }
 #define STORE_W(buf_)                                                              \
   {                                                                                \
     float4* dst_ = reinterpret_cast<float4*>(ws0 + (buf_) * WSP) + tid;            \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k) dst_[k * 256] = wr[k];          \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) dst_[k * NT] = wr[k];           \
   }
 
   f32x16 acc[PSEG][CT];
@@ -528,12 +530,15 @@ int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon
   }
 }
 
+#ifndef CODON_CHAIN_NW
+#define CODON_CHAIN_NW 4
+#endif
 // d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1
 int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* w_chain,
                           const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
-  constexpr int TH = 8;
+  constexpr int NWC = CODON_CHAIN_NW, TH = 2 * NWC;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res ? (const float*)res->data : nullptr;
   p.H = d->height; p.W = d->width;
@@ -553,7 +558,7 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");
 }
 
