@@ -6,6 +6,15 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script starts the N ranks itself: the parent
+makes no GPU call, spawns N fresh `python bench.py` children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+(rendezvous on 127.0.0.1), forwards rank 0's JSON line and exits non-zero if any child fails.
+
+The BASELINE metric has two halves -- "HR depth maps/sec (fwd) + iters/sec (fwd+bwd)": the default line's `value` is
+the exact-fp32 forward (configs[1]); the same line carries `fwd_bwd`: a short training leg at configs[2]'s per-GPU
+shape (x4, batch 32/GPU, 480x640, bf16 activations, fp32 accumulate + master weights, L1+SSIM loss, one RCCL
+all-reduce of the flat gradient per step when N > 1, Adam).
+
 Images are independent units (no op mixes samples), so ranks shard the batch with NO data-path
 collective in forward ("scaling": "weak": 32 images per GPU whatever N).  Rank 0 prints ONE JSON
 line.  `roofline` is measured live for the dominant kernel (the 5x5 128->128 fp32 MFMA conv,
@@ -100,20 +109,20 @@ def cpu_baseline(H, W):
             "config0_1x128x128": {"min_s": c1[0], "median_s": c1[2], "runs": 5}}
 
 
-def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
-    """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP dgrad/wgrad/CAC kernels), ONE
-    all-reduce of the flat gradient buffer (RCCL when world > 1), Adam step.  Nothing is skipped."""
+def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype, scale):
+    """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP
+    dgrad/wgrad/CAC kernels), ONE all-reduce of the flat gradient buffer (RCCL when world > 1), Adam step.
+    Nothing is skipped.  Returns the result dict on rank 0 (None elsewhere)."""
     from codon_amd.dist import GradSync
-    B, H, W = a.batch, a.height, a.width
+    from codon_amd.metrics import L1SSIMLoss
+    B, _, H, W = x.shape
     model.train()
     gs = GradSync(model)
     gs.broadcast_parameters(0)
     opt = torch.optim.Adam(gs.params, lr=1e-4)
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
     tgt = torch.rand((B, 1, H, W), generator=g, device=dev)
-
-    from codon_amd.metrics import L1SSIMLoss
-    crit = L1SSIMLoss(1.0, 1.0)          # BASELINE.json configs[2]: L1 + SSIM (HIP forward + backward, DESIGN.md section 9 f1)
+    crit = L1SSIMLoss(1.0, 1.0)          # BASELINE.json configs[2]: L1 + SSIM (DESIGN.md section 9 f1)
 
     def step():
         gs.zero_grad()
@@ -124,11 +133,12 @@ def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
+    torch.cuda.reset_peak_memory_stats(dev)
+    for _ in range(warmup):
         loss = step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
@@ -137,26 +147,58 @@ def train_bench(a, model, x, y, dev, dist, rank, world, barrier):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    if rank == 0:
-        P = B * H * W
-        step_s = dt / a.steps
-        res = {"metric": "iters/sec (fwd+bwd)", "value": a.steps / dt, "unit": "it/s", "n_gpus": world,
-               "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"CODON x{a.scale} forward+backward (L1 + SSIM loss, Adam), batch {B}/GPU at {H}x{W}, "
-                                      f"{a.dtype}" + (" activations/gradients, fp32 accumulate + master weights "
-                                                      "(BASELINE.json configs[2] per-GPU shape)" if a.dtype == "bf16" else ""),
-                          "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
-                          "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
-               "images_per_s": world * B * a.steps / dt,
-               "whole_step": {"tflops": 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12,
-                              "frac_mfma_peak": 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12 /
-                              (PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS)},
-               "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
-        print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    P = B * H * W
+    step_s = dt / steps
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    tf = 3 * FLOP_PER_PIXEL_FWD * P / step_s / 1e12
+    return {"metric": "iters/sec (fwd+bwd)", "value": steps / dt, "unit": "it/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"CODON x{scale} forward+backward (L1 + SSIM loss, Adam), batch {B}/GPU at {H}x{W}, "
+                                   f"{dtype}" + (" activations/gradients, fp32 accumulate + master weights "
+                                                 "(BASELINE.json configs[2] per-GPU shape)" if dtype == "bf16" else ""),
+                       "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
+                       "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
+            "images_per_s": world * B * steps / dt,
+            "whole_step": {"tflops": tf, "frac_mfma_peak": tf / peak,
+                           "flop_model": "3 x forward FLOPs (SURVEY.md 8d: dgrad + wgrad per conv)"},
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "loss": float(loss),
+            "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+
+
+def self_launch(n, argv):
+    """--gpus N without a launcher: start N fresh rank processes (never an exec of a process that touched the GPU;
+    this parent has made no HIP call).  Rank 0 prints the JSON line on our stdout; any failing child fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:              # exact PIDs we started
+                    q.terminate()
+    if rc != 0:
+        print(f"bench.py: a rank exited with code {rc}", file=sys.stderr)
+    return rc
 
 
 def main():
@@ -169,6 +211,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8, 16])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fwd-bwd", action="store_true",
+                    help="skip the bf16 forward+backward leg (iters/s half of the metric) of the default forward line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo only to rehearse the multi-rank path on one GPU")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -180,11 +224,13 @@ def main():
                     help="fwd: BASELINE metric (maps/s); train: fwd + L1+SSIM loss + bwd + grad all-reduce + Adam step (iters/s)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
@@ -221,7 +267,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     if a.mode == "train":
-        return train_bench(a, model, x, y, dev, dist, rank, world, barrier)
+        res = train_leg(model, x, y, dev, dist, rank, world, barrier, a.steps, a.warmup, a.dtype, a.scale)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     with torch.no_grad():
         for _ in range(a.warmup):
@@ -242,6 +294,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    res = None
     if rank == 0:
         P = B * H * W
         maps_s = world * B * a.steps / dt
@@ -298,6 +351,30 @@ def main():
                 "value": B / dt3, "unit": "maps/s", "ms_per_step": dt3 * 1e3,
                 "rmse_vs_exact_fp32_output": dev_rmse, "output_std": float(out.double().std()),
                 "parity": "passes the same RMSE <= 1e-4 fixtures as the exact path (tests/test_gpu_f16x3.py)"}
+        res["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
+        res["backend"] = (dist.get_backend() if dist is not None else None)
+    if not bf16 and not split and not a.no_fwd_bwd:
+        # second half of the BASELINE metric, every rank takes part (the step holds the RCCL all-reduce): configs[2]'s
+        # per-GPU shape -- same net, same batch/GPU and image size, bf16 activations, fp32 accumulate + master weights
+        del out
+        model = None
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        tm = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev)
+        tm.set_compute_dtype(torch.bfloat16)
+        tsteps = max(3, min(a.steps, 5))
+        leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 1, "bf16", a.scale)
+        del tm
+        torch.cuda.empty_cache()
+        if rank == 0:
+            res["fwd_bwd"] = {"it_per_s": leg["value"], "unit": "it/s (whole job: one optimizer step over the global "
+                              "batch per iteration)", "images_per_s": leg["images_per_s"], "ms_per_step": leg["ms_per_step"],
+                              "steps": leg["steps"], "warmup": leg["warmup"], "dtype": "bf16",
+                              "workload": leg["config"]["workload"], "global_batch": leg["config"]["global_batch"],
+                              "tflops": leg["whole_step"]["tflops"], "frac": leg["whole_step"]["frac_mfma_peak"],
+                              "peak": PEAK_BF16_MFMA_TFLOPS, "rccl_ranks": leg["rccl_ranks"], "loss": leg["loss"],
+                              "peak_mem_gb": leg["peak_mem_gb"]}
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(res), flush=True)

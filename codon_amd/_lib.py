@@ -39,6 +39,7 @@ _TP = C.POINTER(Tensor)
 SIGNATURES = {
     "codon_abi_version": (C.c_int, []),
     "codon_last_error_string": (C.c_char_p, []),
+    "codon_build_source_hash": (C.c_char_p, []),
     "codon_conv_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
     "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "codon_cac_bwd_apply": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _TP, _TP, _TP, _TP,
                                       _I, _I, _P]),
     "codon_postprocess_u8": (C.c_int, [C.c_int64, _P, _P, _P]),
+    "codon_postprocess_u8_dt": (C.c_int, [C.c_int64, _P, C.c_int32, _P, _P]),
     "codon_masked_sqerr": (C.c_int, [C.c_int64, _P, _P, _P, _P]),
     "codon_ssim_tiles": (_I, [_I, _I, _I]),
     "codon_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -104,6 +106,26 @@ def load():
             raise RuntimeError(f"codon_amd: {path} has ABI version {v}, host code expects {ABI_VERSION}")
         _lib = lib
         return lib
+
+
+def build_info() -> dict:
+    """Stale-binary guard: the source hash embedded in the loaded .so vs the hash of the sources now in the tree
+    (same recipe as codon_amd/csrc/Makefile: csrc/*.hip + csrc/*.h in byte-sorted name order, then
+    include/codon_hip.h, contents concatenated, sha256, first 32 hex digits)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files = [os.path.join(csrc, n) for n in names] + [os.path.join(os.path.dirname(here), "include", "codon_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    path = lib_path()
+    return {"path": path, "source_hash_built": load().codon_build_source_hash().decode(),
+            "source_hash_now": h.hexdigest()[:32], "so_mtime": os.path.getmtime(path),
+            "newest_source_mtime": max(os.path.getmtime(f) for f in files)}
 
 
 def check(status: int, what: str):

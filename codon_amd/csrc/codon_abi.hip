@@ -78,6 +78,7 @@ int cac_apply_fwd(int, int, int, const codon_tensor*, const codon_tensor*, const
 int bicubic_upsample(int, int, int, int, const float*, const float*, float*, hipStream_t);
 
 int postprocess_u8(const float*, unsigned char*, long, hipStream_t);
+int postprocess_u8_f16(const void*, unsigned char*, long, hipStream_t);
 int masked_sqerr(const unsigned char*, const unsigned char*, long, unsigned long long*, hipStream_t);
 int ssim_tiles(int, int, int);
 int ssim_fwd(int, int, int, const float*, const float*, float*, float*, double*, hipStream_t);
@@ -97,6 +98,11 @@ extern "C" {
 int codon_abi_version(void) { return CODON_ABI_VERSION; }
 
 const char* codon_last_error_string(void) { return g_err; }
+
+#ifndef CODON_SOURCE_HASH
+#define CODON_SOURCE_HASH "unknown"
+#endif
+const char* codon_build_source_hash(void) { return CODON_SOURCE_HASH; }
 
 size_t codon_conv_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t dtype) {
   if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 5)) return 0;
@@ -392,6 +398,14 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
 int codon_postprocess_u8(int64_t n, const float* x, uint8_t* out, codon_stream_t stream) {
   CODON_REQUIRE(x && out && n > 0, CODON_ERR_BAD_ARG, "postprocess_u8: null pointer or n <= 0");
   return postprocess_u8(x, out, (long)n, (hipStream_t)stream);
+}
+
+int codon_postprocess_u8_dt(int64_t n, const void* x, int32_t dtype, uint8_t* out, codon_stream_t stream) {
+  CODON_REQUIRE(x && out && n > 0, CODON_ERR_BAD_ARG, "postprocess_u8_dt: null pointer or n <= 0");
+  CODON_REQUIRE(dtype == CODON_F32 || dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "postprocess_u8_dt: dtype %d (fp32 or fp16; numpy has no bf16 -- upcast bf16 to fp32 first)", dtype);
+  if (dtype == CODON_F16) return postprocess_u8_f16(x, out, (long)n, (hipStream_t)stream);
+  return postprocess_u8((const float*)x, out, (long)n, (hipStream_t)stream);
 }
 
 int codon_masked_sqerr(int64_t n, const uint8_t* label, const uint8_t* out, uint64_t* acc, codon_stream_t stream) {

@@ -24,6 +24,20 @@ __global__ __launch_bounds__(256) void postprocess_u8_kernel(const float* __rest
   o[i] = (unsigned char)(int)(v * 255.f);
 }
 
+// fp16 network output (the reference script's default: model.cuda().half(), test.py:52): numpy keeps the array in
+// float16, so `out * 255` is ROUNDED TO fp16 (spacing 0.125 in [128,256)) before the truncating cast -- 252.96 becomes
+// 253.0 -> 253, where the fp32 product would give 252.  One fp32 multiply + one rounding to fp16 is exactly numpy's
+// half * half (11-bit x 8-bit significands: the fp32 product is exact).
+__global__ __launch_bounds__(256) void postprocess_u8_f16_kernel(const _Float16* __restrict__ x,
+                                                                 unsigned char* __restrict__ o, long n) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  float v = (float)x[i];
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  const _Float16 p = (_Float16)(v * 255.f);
+  o[i] = (unsigned char)(int)(float)p;
+}
+
 // sum of squared integer differences and count of valid pixels: exact in 64-bit integers, so the result is
 // independent of summation order and equals the reference's float64 loop bit for bit.
 __global__ __launch_bounds__(256) void masked_sqerr_kernel(const unsigned char* __restrict__ label,
@@ -217,6 +231,12 @@ static GaussW make_gauss(double sd) {
 int postprocess_u8(const float* x, unsigned char* o, long n, hipStream_t stream) {
   hipLaunchKernelGGL(postprocess_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, o, n);
   return check_launch("postprocess_u8_kernel");
+}
+
+int postprocess_u8_f16(const void* x, unsigned char* o, long n, hipStream_t stream) {
+  hipLaunchKernelGGL(postprocess_u8_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const _Float16*)x, o, n);
+  return check_launch("postprocess_u8_f16_kernel");
 }
 
 int masked_sqerr(const unsigned char* label, const unsigned char* out, long n, unsigned long long* acc,

@@ -32,6 +32,19 @@ class GradSync:
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
         self._unused = [p for p in model.parameters() if all(p is not q for q in self.params)]
+        self._model = model
+
+    def _install_views(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)                    # a gradient produced outside the buffer: adopt it, then alias
+                p.grad = v
+            off += n
 
     @property
     def world_size(self) -> int:
@@ -43,14 +56,21 @@ class GradSync:
             return
         with torch.no_grad():
             for p in list(self.params) + self._unused:
-                dist.broadcast(p.data, src=src, group=self.group)
+                dist.broadcast(p, src=src, group=self.group)   # on the parameter itself: bumps Tensor._version
+        if hasattr(self._model, "invalidate_packed"):
+            self._model.invalidate_packed()        # packed MFMA weight images of the old values must not survive
 
     def zero_grad(self):
+        """Use this (or optimizer.zero_grad(set_to_none=False)) -- NOT optimizer.zero_grad() with its default
+        set_to_none=True, which drops the .grad views into the flat buffer; all_reduce_grads() re-installs the
+        views if that happened, at the price of one copy per tensor."""
         self.flat.zero_()
+        self._install_views()
 
     def all_reduce_grads(self, async_op: bool = False):
         """Average the flat gradient over ranks.  With a per-image-mean loss on equal shards this equals
         the single-process gradient on the concatenated batch."""
+        self._install_views()                      # no-op when every .grad still aliases the flat buffer
         if not dist.is_initialized() or self.world_size == 1:
             return None
         self.flat.mul_(1.0 / self.world_size)      # pre-scale: the SUM then is the mean, one pass

@@ -25,10 +25,25 @@ class GraphedCODON:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self.model._forward_impl(self.x, self.y, None)
+        # the captured launches carry raw addresses of the packed weight images (ordinary allocator pool) and of the
+        # small fp32 parameters: keep the former alive for the graph's lifetime and remember which weight values
+        # they were packed from, so a replay after a weight update is refused instead of silently stale
+        self._packed_refs = [v[1] for v in self.model._pack_cache.values()]
+        self._tags = self._weight_tags()
+
+    def _weight_tags(self):
+        return [(p.data_ptr(), p._version) for p in self.model.parameters()]
+
+    def stale(self) -> bool:
+        """True when a parameter was replaced or modified (autograd-visibly) after capture.  Writes through `.data`
+        are invisible here, exactly as for the packed-weight cache (model.invalidate_packed)."""
+        return self._weight_tags() != self._tags
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if x.shape != self.x.shape:
             raise RuntimeError(f"GraphedCODON was captured for {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        if self.stale():
+            raise RuntimeError("GraphedCODON: the model's parameters changed after capture; build a new GraphedCODON")
         self.x.copy_(x)
         self.y.copy_(y)
         self.graph.replay()

@@ -20,12 +20,17 @@ def _p(t):
 
 
 def postprocess_u8(x: torch.Tensor) -> torch.Tensor:
+    """np.clip(out, 0, 1); (out * 255).astype(np.uint8) with the product formed in the array's dtype, as numpy
+    does: an fp16 network output (the reference script's default) is rounded to fp16 before the truncating cast
+    (test.py:125-132).  bf16 has no numpy counterpart: it is upcast to fp32."""
     lib = L.load()
+    if x.dtype not in (torch.float32, torch.float16):
+        x = x.float()
+    x = x.contiguous()
     dev = ops._dev(x)
-    x = x.float().contiguous()
     out = torch.empty(x.shape, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        L.check(lib.codon_postprocess_u8(x.numel(), _p(x), _p(out), ops._stream(dev)), "postprocess_u8")
+        L.check(lib.codon_postprocess_u8_dt(x.numel(), _p(x), ops._dt(x), _p(out), ops._stream(dev)), "postprocess_u8")
     return out
 
 

@@ -12,6 +12,7 @@ libcodon_hip.so (see include/codon_hip.h); there is no eager / CPU fallback -- C
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -100,6 +101,7 @@ _MFMA_CONVS = [n for n, ci, co, k in _MAIN_CONVS if ci > 1 and co > 1]
 
 class _CODONBase(nn.Module):
     _HAS_UNUSED_GATE5 = True
+    _warned_fp16_eval = False
 
     def __init__(self):
         super().__init__()
@@ -157,6 +159,23 @@ class _CODONBase(nn.Module):
         self._pack_cache[key] = (tag, packed)
         return packed
 
+    def invalidate_packed(self):
+        """Drop the packed-weight cache.  The cache is keyed on (data_ptr, Tensor._version, device, dtype) of each
+        weight; optimizer steps, load_state_dict, .to()/.half()/.cuda() and every other autograd-visible in-place
+        op change one of those.  Writes THROUGH `.data` (`w.data.normal_()`, `dist.broadcast(w.data)`) do not bump
+        `_version`: after such a write call this method (codon_amd.dist.GradSync does, and load_state_dict / _apply
+        are hooked below)."""
+        self._pack_cache.clear()
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._pack_cache.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pack_cache.clear()
+        return super()._load_from_state_dict(*a, **k)
+
     def _split(self, ksize: int) -> bool:
         return (getattr(self, "conv_precision", "exact") == "f16x3" and ksize in (3, 5)
                 and self._act_dtype() == torch.float32)
@@ -187,10 +206,19 @@ class _CODONBase(nn.Module):
                 raise NotImplementedError("codon_amd.CODONNet: conv_precision='f16x3' is inference-only "
                                           "(the backward kernels are exact fp32); call under torch.no_grad()")
             if adt == torch.float16:
-                raise NotImplementedError("codon_amd.CODONNet: fp16 is inference-only (as in the reference, "
-                                          "test.py:52); train in fp32 or bf16, or call under torch.no_grad()")
-            from .autograd import codon_apply  # training path (custom backward)
-            return codon_apply(self, x, y)
+                # the reference script itself does this: model.cuda().half(), model.eval(), then model(x, y) with
+                # grad mode on (test.py:52,66,125).  fp16 has no backward here, so in eval mode the call is served
+                # by the inference schedule and returns a detached output; in train mode it is refused.
+                if self.training:
+                    raise NotImplementedError("codon_amd.CODONNet: fp16 is inference-only (as in the reference, "
+                                              "test.py:52); train in fp32 or bf16, or call .eval() first")
+                if not _CODONBase._warned_fp16_eval:
+                    _CODONBase._warned_fp16_eval = True
+                    warnings.warn("codon_amd.CODONNet: fp16 forward in eval mode with grad enabled runs the inference "
+                                  "kernels and returns a detached output (no fp16 backward exists)", stacklevel=2)
+            else:
+                from .autograd import codon_apply  # training path (custom backward)
+                return codon_apply(self, x, y)
         out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)
         return out if x.dtype == torch.float32 else out.to(x.dtype)
 
@@ -342,6 +370,15 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
     _packed = _CODONBase._packed
     _split = _CODONBase._split
     __getstate__ = _CODONBase.__getstate__
+    invalidate_packed = _CODONBase.invalidate_packed
+
+    def _apply(self, fn, *a, **k):
+        self._pack_cache.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pack_cache.clear()
+        return super()._load_from_state_dict(*a, **k)
 
     def forward(self, x, y):
         if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 1:

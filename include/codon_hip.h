@@ -73,6 +73,9 @@ typedef struct codon_tensor {
 
 int codon_abi_version(void);
 const char* codon_last_error_string(void);
+/* first 32 hex digits of sha256 over the sources this binary was built from (codon_amd/csrc/{*.hip,*.h} in byte-sorted
+ * name order, then include/codon_hip.h, contents concatenated): lets a host detect a stale binary. */
+const char* codon_build_source_hash(void);
 
 /* ---- MFMA implicit-GEMM convolutions (99.9 % of the FLOPs) -------------------------------
  * replaces: self.relu(self.conv{1..11}(..)), self.conv_input(_c), self.confuse(_c/_fuse)
@@ -235,6 +238,9 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
  * l1_fwd         : value[0] (double) = mean |a - b| ; partial: nparts floats scratch
  * ssim_l1_bwd    : ga = ssim_scale * d(sum SSIM)/da + l1_scale * sign(a - b); tmp: (B,3,H,W) scratch; H,W >= 7 */
 int codon_postprocess_u8(int64_t n, const float* x, uint8_t* out, codon_stream_t stream);
+/* same, with the product formed in the ARRAY'S dtype as numpy does: dtype CODON_F16 rounds clip(x)*255 to fp16
+ * before truncating (the reference's default fp16 path, test.py:52,125-132); CODON_F32 == codon_postprocess_u8. */
+int codon_postprocess_u8_dt(int64_t n, const void* x, int32_t dtype, uint8_t* out, codon_stream_t stream);
 int codon_masked_sqerr(int64_t n, const uint8_t* label, const uint8_t* out, uint64_t* acc,
                        codon_stream_t stream);
 int32_t codon_ssim_tiles(int32_t batch, int32_t height, int32_t width);

@@ -16,8 +16,10 @@ import torch
 
 def postprocess_u8(x):
     """out = np.clip(out, 0, 1); out = (out * 255).astype(np.uint8)   (test.py:130-132; float32 product)."""
-    x = np.asarray(x, dtype=np.float32)
-    return (np.clip(x, 0, 1) * np.float32(255)).astype(np.uint8)
+    x = np.asarray(x)
+    if x.dtype != np.float16:                       # fp16 arrays keep their dtype, exactly as in the reference script
+        x = x.astype(np.float32)
+    return (np.clip(x, 0, 1) * 255).astype(np.uint8)
 
 
 def masked_rmse(label, out):

@@ -51,6 +51,51 @@ def test_io_roundtrip_and_checkpoint_formats(tmp_path):
     assert torch.equal(s16.conv3.weight, d16.conv3.weight)
 
 
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the read-only reference tree (build container only)")
+@pytest.mark.parametrize("sub,mod,n_keys", [("CODON_X4", "CODON_x4", 49), ("CODON_X8", "CODON_x8", 49),
+                                            ("CODON_X16", "CODON_x16", 44)])
+def test_genuine_reference_checkpoint_unpickles(tmp_path, sub, mod, n_keys):
+    """The format test.py:56-59 loads is {"epoch", "model": <the REFERENCE's CODONNet instance>}: its pickle names
+    CODON_x4.CODONNet, CAC_module.* and (x4/x8) attention.ResCBAM.ChannelGate/Flatten.  Save one from the imported
+    reference in a child process, load it here through codon_amd/compat."""
+    import subprocess
+    ck = str(tmp_path / "ref.pth")
+    code = (f"import sys; sys.dont_write_bytecode = True; import torch; torch.manual_seed(5); import {mod}; "
+            f"m = {mod}.CODONNet(); torch.save({{'epoch': 93, 'model': m}}, {ck!r}); "
+            f"torch.save(m.state_dict(), {ck!r} + '.sd')")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=os.path.join(REF, sub), timeout=300,
+                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    from codon_amd import CODONNet, CODONNet16, io
+    dst = (CODONNet16 if n_keys == 44 else CODONNet)()
+    assert io.load_checkpoint(ck, dst) == 93
+    ref_sd = torch.load(ck + ".sd", map_location="cpu")
+    assert list(ref_sd.keys()) == list(dst.state_dict().keys()) and len(ref_sd) == n_keys
+    assert all(torch.equal(ref_sd[k], v) for k, v in dst.state_dict().items())
+
+
+def test_pack_cache_invalidation_hooks():
+    """writes through .data do not bump Tensor._version; invalidate_packed() / load_state_dict / _apply
+    must drop the packed images (CPU-checkable: the cache dict itself)."""
+    from codon_amd import CODONNet
+    m = CODONNet()
+    v0 = m.conv1.weight._version
+    m.conv1.weight.data.normal_()
+    assert m.conv1.weight._version == v0              # the hazard
+    m._pack_cache["probe"] = ("tag", torch.zeros(1))
+    m.invalidate_packed()
+    assert not m._pack_cache
+    m._pack_cache["probe"] = ("tag", torch.zeros(1))
+    m.load_state_dict(m.state_dict())
+    assert not m._pack_cache
+    m._pack_cache["probe"] = ("tag", torch.zeros(1))
+    m.double()
+    assert not m._pack_cache
+    m.float()
+
+
 @pytest.mark.gpu
 def test_rmcr_ablation_matches_golden():
     from codon_amd import BaseNet_RMCR_fuseRMCR

@@ -37,6 +37,17 @@ def test_oracle_postprocess_truncates():
     assert mo.postprocess_u8(x).tolist() == [0, 0, 127, 254, 255, 255, 254]
 
 
+def test_oracle_postprocess_fp16_rounds_product_to_half():
+    """The reference script's default path keeps the output in float16 (test.py:52,125-132): out * 255 is rounded
+    to fp16 before the truncating cast.  0.99219 (fp16) * 255 = 253.008 -> 253; 0.9917 * 255 = 252.88 -> fp16 252.875."""
+    h = np.array([0.992, 0.9917, 0.5, 1.0, 0.0], dtype=np.float16)
+    got = mo.postprocess_u8(h)
+    assert got.dtype == np.uint8 and got.tolist() == (np.clip(h, 0, 1) * 255).astype(np.uint8).tolist()
+    # there are fp16 values whose fp32 product truncates differently: the two paths are not the same function
+    allh = np.arange(0, 0x3c01, dtype=np.uint16).view(np.float16)          # every fp16 in [0, 1]
+    assert (mo.postprocess_u8(allh) != mo.postprocess_u8(allh.astype(np.float32))).any()
+
+
 def test_ssim_torch_equals_numpy_oracle(z):
     a, b = z["Art.output"] / 255.0, z["Art.label"] / 255.0
     t = mo.ssim_torch(torch.from_numpy(a)[None, None], torch.from_numpy(b)[None, None])
@@ -64,6 +75,19 @@ def test_hip_postprocess_bit_exact():
     x = np.concatenate([g.uniform(-0.2, 1.2, 100000), np.arange(0, 256) / 255.0, [0.0, 1.0, -0.0, 0.5]]).astype(np.float32)
     got = metrics.postprocess_u8(torch.from_numpy(x).cuda()).cpu().numpy()
     assert np.array_equal(got, mo.postprocess_u8(x))
+
+
+@pytest.mark.gpu
+def test_hip_postprocess_fp16_bit_exact_all_halves():
+    """Every finite fp16 bit pattern (and the infinities): the fp16 entry equals numpy's float16 arithmetic."""
+    from codon_amd import metrics
+    bits = np.concatenate([np.arange(0, 0x7c01, dtype=np.uint16), np.arange(0x8000, 0xfc01, dtype=np.uint16)])
+    h = bits.view(np.float16)
+    got = metrics.postprocess_u8(torch.from_numpy(h.copy()).cuda()).cpu().numpy()
+    assert np.array_equal(got, mo.postprocess_u8(h))
+    # bf16 outputs are upcast (numpy has no bf16)
+    x = torch.rand(1000, device="cuda").bfloat16()
+    assert np.array_equal(metrics.postprocess_u8(x).cpu().numpy(), mo.postprocess_u8(x.float().cpu().numpy()))
 
 
 @pytest.mark.gpu

@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 # network fixtures (tools/make_golden.py); metrics_crops.npz and rmcr_kat0.npz have their own tests
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.split("_")[0] in ("kat0", "he0", "he1"))
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.split("_")[0] in ("kat0", "he0", "he1", "he2"))
+# the reference MODULE run in bfloat16 on CPU (tools/make_golden_r2.py): pins the bf16 tolerance
+BF16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16ref_") and f.endswith(".npz"))
 
 
 def load_case(name):
@@ -21,7 +23,7 @@ def load_case(name):
     if wkind == "kat":
         sd = orc.kat_state(variant)
     else:
-        sd = orc.he_state(variant, seed={"he": 0, "he1": 1}[wkind])
+        sd = orc.he_state(variant, seed={"he": 0, "he1": 1, "he2": 2}[wkind])
     x, y = orc.kat_inputs(B, H, W)
     return z, variant, sd, x, y
 
