@@ -165,7 +165,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "whole_step": {"tflops": tf, "frac_mfma_peak": tf / peak,
                            "flop_model": "3 x forward FLOPs (SURVEY.md 8d: dgrad + wgrad per conv)"},
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
-            "loss": float(loss),
+            "loss": float(loss.detach()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
 
 
