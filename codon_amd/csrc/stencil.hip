@@ -5,6 +5,8 @@
 // contiguous bytes per load/store instruction (1 KiB at VEC=4).  VEC=4 needs W % 4 == 0 (every
 // plane row is then 16-byte aligned); other widths take the VEC=1 instantiation.
 
+#include <type_traits>
+
 #include "codon_common.h"
 #include "px8.h"
 
@@ -134,55 +136,152 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   }
 }
 
-template <int VEC, typename T>
+// head: y = sum_c conv3x3(x_c, w_c) + res.  One thread owns VEC consecutive pixels of R consecutive rows (a band): per
+// channel it loads the band's R + 2 rows ONCE and produces all R output rows from registers, so an input element is
+// fetched (R + 2) / R times instead of 3 (round 1: one row per thread, 6.08 GB moved for 2.60 GB algorithmic -- the
+// vertically adjacent rows sat in other workgroups on other XCDs, whose L2s each fetched them again).
+// 16-bit activations take VEC = 8 (16-byte accesses), fp32 VEC = 4; VEC = 1 for widths that are not a multiple.
+template <int VEC, int R, typename T>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ res, float* __restrict__ y, int H,
-                                                   int W, long x_img, long x_base, long total) {
+                                                   int W, long x_img, long x_base, int nband, int nseg, int nwave,
+                                                   int nblk) {
   __shared__ float wsh[64 * 9];
   for (int i = threadIdx.x; i < 576; i += 256) wsh[i] = w[i];
   __syncthreads();
-  const long idx = blockIdx.x * 256L + threadIdx.x;
-  if (idx >= total) return;
+  // a WAVE owns one (image, band of R rows, segment of 64 * VEC columns): lane neighbours are pixel neighbours, so the
+  // two halo columns of a lane's vector come from the adjacent lanes (ds_bpermute), not from memory; only lanes 0 and 63
+  // fetch theirs.  Consecutive waves walk a band, then the next band of the image: with the XCD remap vertically adjacent
+  // bands (which share their 2 halo rows) sit in the same XCD's L2.
+  const int lane = threadIdx.x & 63;
+  // readfirstlane: the wave index is wave-uniform but hipcc cannot prove it (threadIdx.x >> 6); left as a VGPR value it
+  // wraps every buffer load in a waterfall loop over "distinct" descriptors / scalar offsets + s_waitcnt vmcnt(0)
+  const int wid = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, (unsigned)nblk) * 4 + (int)(threadIdx.x >> 6));
+  if (wid >= nwave) return;
+  const int seg = wid % nseg;
+  const int t = wid / nseg;
+  const int band = t % nband, b = t / nband;
   const int WV = W / VEC;
-  const int gxv = (int)(idx % WV);
-  const long t = idx / WV;
-  const int gy = (int)(t % H);
-  const int b = (int)(t / H);
-  const int gx0 = gxv * VEC;
+  const int gxv = seg * 64 + lane;
+  const bool act = gxv < WV;
+  const int gx0 = act ? gxv * VEC : 0, gy0 = band * R;
   const long HW = (long)H * W;
   const T* xb = x + (long)b * x_img + x_base;
-  float o[VEC];
+  const bool ldl = act && lane == 0 && gx0 > 0;                 // this lane's left / right halo column comes from memory
+  const bool ldr = act && lane == 63 && gx0 + VEC < W;
+  const bool shl = lane > 0, shr = lane < 63 && gx0 + VEC < W;  // ... or from the neighbouring lane
+  float o[R][VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) o[i] = 0.f;
-#pragma unroll 2
-  for (int c = 0; c < 64; ++c) {
-    const T* plane = xb + c * HW;
-    const float* k = wsh + c * 9;
-    float r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
-    load_row<VEC, T>(plane, gy - 1, gx0, H, W, r0);
-    load_row<VEC, T>(plane, gy, gx0, H, W, r1);
-    load_row<VEC, T>(plane, gy + 1, gx0, H, W, r2);
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float a = o[i];
-      a = fmaf(k[0], r0[i], a);
-      a = fmaf(k[1], r0[i + 1], a);
-      a = fmaf(k[2], r0[i + 2], a);
-      a = fmaf(k[3], r1[i], a);
-      a = fmaf(k[4], r1[i + 1], a);
-      a = fmaf(k[5], r1[i + 2], a);
-      a = fmaf(k[6], r2[i], a);
-      a = fmaf(k[7], r2[i + 1], a);
-      a = fmaf(k[8], r2[i + 2], a);
-      o[i] = a;
+    for (int i = 0; i < VEC; ++i) o[r][i] = 0.f;
+
+  // Every load is an unconditional buffer instruction: `cond ? load : 0` compiles to a branch and an s_waitcnt vmcnt(0)
+  // PER LOAD (one memory round trip each).  Lanes that must not load carry an out-of-range offset (returns 0, no
+  // traffic); rows outside the image take a zero-length descriptor (wave-uniform SGPR select); the (channel, row) term
+  // of the address is a scalar offset.
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int ES = (int)sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)(64u * (unsigned)HW * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nil = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0, 0x00020000);
+  const unsigned vo = act ? (unsigned)gx0 * ES : OOB;
+  const unsigned vl = ldl ? (unsigned)(gx0 - 1) * ES : OOB;
+  const unsigned vr = ldr ? (unsigned)(gx0 + VEC) * ES : OOB;
+  auto load_rows = [&](int c, float (&rw)[R + 2][VEC + 2]) {
+#pragma unroll
+    for (int j = 0; j < R + 2; ++j) {
+      const int gy = gy0 - 1 + j;
+      const bool rowok = gy >= 0 && gy < H;                       // wave-uniform
+      const __amdgpu_buffer_rsrc_t rs = rowok ? rs_img : rs_nil;
+      const unsigned so = ((unsigned)c * (unsigned)HW + (unsigned)(rowok ? gy : 0) * (unsigned)W) * ES;
+      if constexpr (ES == 4) {
+        if constexpr (VEC == 4) {
+          const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+          const float4 f = *reinterpret_cast<const float4*>(&v);
+          rw[j][1] = f.x; rw[j][2] = f.y; rw[j][3] = f.z; rw[j][4] = f.w;
+        } else if constexpr (VEC == 2) {
+          const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+          const float2 f = *reinterpret_cast<const float2*>(&v);
+          rw[j][1] = f.x; rw[j][2] = f.y;
+        } else {
+          rw[j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+        }
+        rw[j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vl, so, 0));
+        rw[j][VEC + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vr, so, 0));
+      } else {
+        typedef typename std::conditional<std::is_same<T, h16_t>::value, CvtH16, CvtB16>::type CV;
+        if constexpr (VEC == 8) {
+          const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+          const uint4 q = *reinterpret_cast<const uint4*>(&v);
+          rw[j][1] = CV::lo(q.x); rw[j][2] = CV::hi(q.x); rw[j][3] = CV::lo(q.y); rw[j][4] = CV::hi(q.y);
+          rw[j][5] = CV::lo(q.z); rw[j][6] = CV::hi(q.z); rw[j][7] = CV::lo(q.w); rw[j][8] = CV::hi(q.w);
+        } else if constexpr (VEC == 4) {
+          const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+          const uint2 q = *reinterpret_cast<const uint2*>(&v);
+          rw[j][1] = CV::lo(q.x); rw[j][2] = CV::hi(q.x); rw[j][3] = CV::lo(q.y); rw[j][4] = CV::hi(q.y);
+        } else if constexpr (VEC == 2) {
+          const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+          rw[j][1] = CV::lo(q); rw[j][2] = CV::hi(q);
+        } else {
+          rw[j][1] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0));
+        }
+        rw[j][0] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vl, so, 0));
+        rw[j][VEC + 1] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vr, so, 0));
+      }
     }
+  };
+  auto accumulate = [&](int c, float (&rw)[R + 2][VEC + 2]) {
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = wsh[c * 9 + j];
+#pragma unroll
+    for (int j = 0; j < R + 2; ++j) {
+      const float fl = __shfl_up(rw[j][VEC], 1, 64), fr = __shfl_down(rw[j][1], 1, 64);
+      rw[j][0] = shl ? fl : rw[j][0];
+      rw[j][VEC + 1] = shr ? fr : rw[j][VEC + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float a = o[r][i];           // same tap order as round 1: results unchanged bit for bit
+        a = fmaf(k[0], rw[r][i], a);
+        a = fmaf(k[1], rw[r][i + 1], a);
+        a = fmaf(k[2], rw[r][i + 2], a);
+        a = fmaf(k[3], rw[r + 1][i], a);
+        a = fmaf(k[4], rw[r + 1][i + 1], a);
+        a = fmaf(k[5], rw[r + 1][i + 2], a);
+        a = fmaf(k[6], rw[r + 2][i], a);
+        a = fmaf(k[7], rw[r + 2][i + 1], a);
+        a = fmaf(k[8], rw[r + 2][i + 2], a);
+        o[r][i] = a;
+      }
+  };
+#pragma unroll 1
+  for (int c = 0; c < 64; ++c) {
+    float ra[R + 2][VEC + 2];
+    load_rows(c, ra);
+    accumulate(c, ra);
   }
-  const long off = (long)b * HW + (long)gy * W + gx0;
-  if constexpr (VEC == 4) {
-    const float4 r = *reinterpret_cast<const float4*>(res + off);
-    *reinterpret_cast<float4*>(y + off) = make_float4(o[0] + r.x, o[1] + r.y, o[2] + r.z, o[3] + r.w);
-  } else {
-    y[off] = o[0] + res[off];
+  if (!act) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int gy = gy0 + r;
+    if (gy >= H) break;
+    const long off = (long)b * HW + (long)gy * W + gx0;
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const float4 rr = *reinterpret_cast<const float4*>(res + off + 4 * q);
+        *reinterpret_cast<float4*>(y + off + 4 * q) = make_float4(o[r][4 * q] + rr.x, o[r][4 * q + 1] + rr.y,
+                                                                  o[r][4 * q + 2] + rr.z, o[r][4 * q + 3] + rr.w);
+      }
+    } else if constexpr (VEC == 2) {
+      const float2 rr = *reinterpret_cast<const float2*>(res + off);
+      *reinterpret_cast<float2*>(y + off) = make_float2(o[r][0] + rr.x, o[r][1] + rr.y);
+    } else {
+      y[off] = o[r][0] + res[off];
+    }
   }
 }
 
@@ -216,22 +315,48 @@ int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y
                             stream);
 }
 
+template <int VEC, int R, typename T>
+static int head_launch_v(int B, int H, int W, const T* x, int x_ctotal, int x_coff, const float* w, const float* res,
+                         float* y, hipStream_t stream) {
+  const long HW = (long)H * W;
+  const int nband = (H + R - 1) / R;
+  const int nseg = (W / VEC + 63) / 64;
+  const long nwave = (long)B * nband * nseg;
+  const long blocks = (nwave + 3) / 4;
+  CODON_REQUIRE(nwave < (1L << 31), CODON_ERR_UNSUPPORTED, "head_fwd: grid too large");
+  hipLaunchKernelGGL((head_kernel<VEC, R, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
+                     x_ctotal * HW, x_coff * HW, nband, nseg, (int)nwave, (int)blocks);
+  return check_launch("head_kernel");
+}
+
 template <typename T>
 static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff, const float* w, const float* res,
                        float* y, hipStream_t stream) {
   const long HW = (long)H * W;
-  const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
-                                    reinterpret_cast<uintptr_t>(res)) % 16 == 0);
-  const long total = (long)B * H * (v4 ? W / 4 : W);
-  const long blocks = (total + 255) / 256;
-  CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "head_fwd: grid too large");
+  CODON_REQUIRE(64 * HW * (long)sizeof(T) < 0xFFFFFFF0L, CODON_ERR_UNSUPPORTED,
+                "head_fwd: %dx%d image: 64 channel planes exceed the 4 GiB buffer-descriptor range", H, W);
+  // 16-byte (fp32) / 8-byte (16-bit) row accesses need every plane row start aligned to them
+  const uintptr_t al = sizeof(T) == 4 ? 16 : 8;
+  const bool v4 = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % al == 0) &&
+                  ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) % 16 == 0) &&
+                  ((x_ctotal * HW * sizeof(T)) % al == 0) && ((x_coff * HW * sizeof(T)) % al == 0);
+#ifdef CODON_TUNE
+  if (const char* e = getenv("CODON_HEAD_BAND")) {
+    const int r = atoi(e);
+#define HV(v_, r_) if (r == v_ * 100 + r_) return head_launch_v<v_, r_, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
+    if constexpr (sizeof(T) == 2) { HV(8, 2) HV(8, 4) HV(8, 8) }
+    HV(2, 4) HV(2, 8) HV(2, 16) HV(4, 2) HV(4, 4) HV(4, 8) HV(4, 16)
+#undef HV
+  }
+#endif
+  // band height R: an input row is fetched (R + 2) / R times.  Measured at 32 x 64 x 480 x 640 (tools/time_head.py, one box):
+  // fp32 R = 4 / 8 / 16: 0.531 / 0.468 / 0.462 ms; bf16: 0.429 / 0.393 / 0.345 ms (round 1: 1.11 / 1.30 ms).  Small
+  // images keep R = 4 (more waves).
+  const bool big = (long)B * H * W >= (1L << 22);
   if (v4)
-    hipLaunchKernelGGL((head_kernel<4, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
-                       x_ctotal * HW, x_coff * HW, total);
-  else
-    hipLaunchKernelGGL((head_kernel<1, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
-                       x_ctotal * HW, x_coff * HW, total);
-  return check_launch("head_kernel");
+    return big ? head_launch_v<4, 16, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream)
+               : head_launch_v<4, 4, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
+  return head_launch_v<1, 4, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
 }
 
 int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
