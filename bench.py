@@ -220,6 +220,10 @@ def main():
     ap.add_argument("--conv-precision", choices=["exact", "f16x3"], default="exact",
                     help="fp32 only. exact (default): fp32 MFMA. f16x3: OPT-IN split-precision convs (3 f16 MFMAs per "
                          "product, fp32 accumulate, ~2^-22 per product) -- reported with its own dtype label")
+    ap.add_argument("--model", choices=["codon", "rmcr"], default="codon",
+                    help="codon (default): CODONNet. rmcr: the conv-only ablation BaseNet_RMCR_fuseRMCR "
+                         "(CODON_X16/CODON_x16.py:16-90, SURVEY 8f row f4) -- same 19 convs, no CAC gates: the pure-conv "
+                         "roofline probe; forward only")
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd",
                     help="fwd: BASELINE metric (maps/s); train: fwd + L1+SSIM loss + bwd + grad all-reduce + Adam step (iters/s)")
     a = ap.parse_args()
@@ -246,10 +250,13 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from codon_amd import CODONNet, CODONNet16, ops
+    from codon_amd import BaseNet_RMCR_fuseRMCR, CODONNet, CODONNet16, ops
     B, H, W = a.batch, a.height, a.width
     torch.manual_seed(0)
-    model = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev).eval()   # reference init rule, seed 0
+    rmcr = a.model == "rmcr"
+    if rmcr and a.mode != "fwd":
+        raise SystemExit("bench.py: --model rmcr is forward only")
+    model = (BaseNet_RMCR_fuseRMCR if rmcr else CODONNet16 if a.scale == 16 else CODONNet)().to(dev).eval()   # reference init rule, seed 0
     bf16 = a.dtype == "bf16"
     if bf16:
         model.set_compute_dtype(torch.bfloat16)
@@ -332,7 +339,7 @@ def main():
                               "frac_hbm_peak": ALG_ELEMS_PER_PIXEL * esize * P / step_s / 1e9 / PEAK_HBM_GBS,
                               "mpx_per_s": world * P / step_s / 1e6},
         }
-        if world == 1 and not bf16 and not split and a.mode == "fwd":
+        if world == 1 and not bf16 and not split and a.mode == "fwd" and not rmcr:
             # OPT-IN mode, reported beside (never instead of) the exact-fp32 headline: same inputs, same K steps
             model.set_conv_precision("f16x3")
             with torch.no_grad():
@@ -353,7 +360,17 @@ def main():
                 "parity": "passes the same RMSE <= 1e-4 fixtures as the exact path (tests/test_gpu_f16x3.py)"}
         res["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
         res["backend"] = (dist.get_backend() if dist is not None else None)
-    if not bf16 and not split and not a.no_fwd_bwd:
+    if rank == 0 and rmcr:
+        # no CAC gates: 5 x (518 activation elements + 250 MAC of the 5x5 2->1 spatial conv) less per pixel
+        step_s_ = dt / a.steps
+        fl_, el_ = FLOP_PER_PIXEL_FWD - 5 * 500, ALG_ELEMS_PER_PIXEL - 5 * 518
+        res["whole_forward"].update({"tflops": fl_ * B * H * W / step_s_ / 1e12,
+                                     "frac_mfma_peak": fl_ * B * H * W / step_s_ / 1e12 / peak_mfma,
+                                     "alg_hbm_gbs": el_ * esize * B * H * W / step_s_ / 1e9,
+                                     "frac_hbm_peak": el_ * esize * B * H * W / step_s_ / 1e9 / PEAK_HBM_GBS})
+        res["config"]["workload"] = res["config"]["workload"].replace("CODON x", "BaseNet_RMCR_fuseRMCR (conv-only ablation, no CAC gates) x")
+        res["metric"] = "HR depth maps/sec (fwd), conv-only ablation"
+    if not bf16 and not split and not a.no_fwd_bwd and not rmcr:
         # second half of the BASELINE metric, every rank takes part (the step holds the RCCL all-reduce): configs[2]'s
         # per-GPU shape -- same net, same batch/GPU and image size, bf16 activations, fp32 accumulate + master weights
         del out
