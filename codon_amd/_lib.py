@@ -80,7 +80,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """In-tree library; CODON_AMD_LIB names another build of it (kernel A/B timing, tools/ab_build.sh)."""
+    return os.environ.get("CODON_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 def load():

@@ -108,10 +108,23 @@ enum { RES16_NONE = 0, RES16_ADD = 1, RES16_MASK = 2 };
 // pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is 8 MFMAs
 // on 6 operand fetches (0.75 ds_read_b128 per MFMA instead of 1.0 -- LDS bandwidth is what these kernels run out of)
 // Measured A/B on one box: conv5x5 64->64 2.21 -> 2.05 ms; the 3x3 convs (3 taps per stage) do not gain (1.09 -> 1.10).
-template <int KS, int COUT> struct Conv16Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : 2; };
+#ifndef CODON_PSEG3
+#define CODON_PSEG3 2
+#endif
+#ifndef CODON_RPS3
+#define CODON_RPS3 3
+#endif
+template <int KS, int COUT> struct Conv16Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_PSEG3 : 2; };
+// filter rows per stage: the 3x3 64-cout convs take all three (one barrier per 16-channel chunk, 36 MFMAs per wave
+// between barriers instead of 12 -- with one row per stage these kernels spent their time at the barrier: 30 % of the
+// matrix peak and 33 % of HBM, bound by neither)
+template <int KS, int COUT> struct Conv16Rps { static constexpr int value = (KS == 3 && COUT == 64) ? CODON_RPS3 : 1; };
 
+#ifndef CODON_OCC3
+#define CODON_OCC3 2
+#endif
 template <class E, int KS, int CIN, int COUT, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Params p) {
+__global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
   typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
@@ -121,10 +134,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = 16, NCB = CK / 8;
   constexpr int NCHUNK = CIN / CK;
+  constexpr int RPS = Conv16Rps<KS, COUT>::value;   // filter rows per stage
+  constexpr int SPC = KS / RPS;                     // stages per chunk
+  static_assert(SPC * RPS == KS, "rows per stage divides the filter height");
   constexpr int XS = NCB * XR * XQ;       // 16-byte elements per input tile
-  constexpr int WS = KS * NCB * COUT;     // 16-byte elements per weight stage
+  constexpr int WS = RPS * KS * NCB * COUT;     // 16-byte elements per weight stage
   constexpr int CT = COUT / 32;
-  constexpr int NST = NCHUNK * KS;
+  constexpr int NST = NCHUNK * SPC;
   constexpr int XE = (XS + 255) / 256;    // 16-byte elements (8 channels of a pixel) per thread per chunk
   constexpr int WE = (WS + 255) / 256;
   constexpr int XSP = XE * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   const lds_rd wrd = (lds_rd)(ws0 + half * COUT + l31);
 
   // the next chunk's halo tile is fetched in two halves, during the last two filter rows of the current chunk
-  constexpr int XE1 = (KS >= 3) ? XE / 2 : 0, XEH = XE - XE1;
+  constexpr int XE1 = (KS >= 3 && SPC >= 2) ? XE / 2 : 0, XEH = XE - XE1;
   u16 xv[XEH][8];
   u32x4 wr[WE];
 
@@ -240,19 +256,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
   // in xs[chunk & 1].  Unrolled over (chunk parity, dy): KS odd, so the stage parity is (par + dy) & 1.
 #pragma unroll 1
   for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
-    static_for16<2 * KS>([&](auto uc) {
+    static_for16<2 * SPC>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      constexpr int par = u / KS, dy = u % KS;
-      constexpr int sbuf = (par + dy) & 1;
+      constexpr int par = u / SPC, dyg = u % SPC;                 // chunk parity, stage within the chunk
+      constexpr int sbuf = (par * SPC + dyg) & 1;                 // c2 is even: stage parity is compile time
       const int chunk = c2 + par;
-      const int s = chunk * KS + dy;
-      constexpr bool tail = (par == 1 && dy == KS - 1);           // last stage of the pair
+      const int s = chunk * SPC + dyg;
+      constexpr bool tail = (par == 1 && dyg == SPC - 1);         // last stage of the pair
       const bool has_next = !tail || (c2 + 2 < NCHUNK);
       if (has_next) {
         LOAD_W(s + 1);
-        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, XE1, XE);
+        if constexpr (dyg == SPC - 1) LOAD_X(chunk + 1, XE1, XE);
       }
-      if constexpr (XE1 > 0 && dy == KS - 2) {
+      if constexpr (XE1 > 0 && dyg == SPC - 2) {
         if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, 0, XE1);
       }
 
@@ -261,42 +277,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(const Conv16Para
       // wins on the 8-MFMA taps of conv5x5-128 (6.59 vs 6.75 ms), unpinned on the 3x3 convs (1.13 vs 1.21 ms).
       constexpr bool PIN = (KS == 5 && PSEG * CT == 8);
       vec8 a[2][CT], bv[2][PSEG];
-#define FETCH_A(dx_, t_)                                                                                  \
+      // tap index q = rr * KS + dx walks the stage's RPS filter rows; dy = dyg * RPS + rr
+#define FETCH_A(q_, t_)                                                                                   \
   {                                                                                                       \
-    const u32x4 v_ = wrd[sbuf * WSP + (dx_) * NCB * COUT + (t_) * 32];                                    \
-    a[(dx_) & 1][t_] = *reinterpret_cast<const vec8*>(&v_);                                               \
+    const u32x4 v_ = wrd[sbuf * WSP + (q_) * NCB * COUT + (t_) * 32];                                     \
+    a[(q_) & 1][t_] = *reinterpret_cast<const vec8*>(&v_);                                                \
   }
-#define FETCH_B(dx_)                                                                                      \
+#define FETCH_B(q_)                                                                                       \
   {                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < PSEG; ++i) {                                                    \
-      const u32x4 v_ = xrd[par * XSP + (dy + i) * XQ + (dx_)];                                            \
-      bv[(dx_) & 1][i] = *reinterpret_cast<const vec8*>(&v_);                                             \
+      const u32x4 v_ = xrd[par * XSP + (dyg * RPS + (q_) / KS + i) * XQ + ((q_) % KS)];                   \
+      bv[(q_) & 1][i] = *reinterpret_cast<const vec8*>(&v_);                                              \
     }                                                                                                     \
   }
       static_for16<CT>([&](auto tc) { FETCH_A(0, decltype(tc)::value) });
       FETCH_B(0)
-      static_for16<KS>([&](auto dc) {
-        constexpr int dx = decltype(dc)::value;
-        if constexpr (dx + 1 < KS) {
-          FETCH_B(dx + 1)
-          static_for16<CT>([&](auto tc) { FETCH_A(dx + 1, decltype(tc)::value) });
+      static_for16<RPS * KS>([&](auto dc) {
+        constexpr int q = decltype(dc)::value;
+        if constexpr (q + 1 < RPS * KS) {
+          FETCH_B(q + 1)
+          static_for16<CT>([&](auto tc) { FETCH_A(q + 1, decltype(tc)::value) });
         }
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
-          for (int i = 0; i < PSEG; ++i) acc[i][t] = E::mfma(a[dx & 1][t], bv[dx & 1][i], acc[i][t]);
+          for (int i = 0; i < PSEG; ++i) acc[i][t] = E::mfma(a[q & 1][t], bv[q & 1][i], acc[i][t]);
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       });
 #undef FETCH_A
 #undef FETCH_B
 
-      if constexpr (XE1 > 0 && dy == KS - 2) {
+      if constexpr (XE1 > 0 && dyg == SPC - 2) {
         if (!(par == 1 && c2 + 2 >= NCHUNK)) STORE_X(par ^ 1, 0, XE1);
       }
       if (has_next) {
         STORE_W(sbuf ^ 1);
-        if constexpr (dy == KS - 1) STORE_X(par ^ 1, XE1, XE);
+        if constexpr (dyg == SPC - 1) STORE_X(par ^ 1, XE1, XE);
       }
       __syncthreads();
     });

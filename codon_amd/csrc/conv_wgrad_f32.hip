@@ -181,8 +181,15 @@ int launch_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps,
   return check_launch("wgrad_reduce_kernel");
 }
 
+// conv_wgrad_f32_t16.hip: 16x16x4 tiles, 8 balanced waves, double-buffered (W % 4 == 0, 16-byte aligned slices, k in {3,5})
+bool conv_wgrad_f32_t16_shape(const codon_conv_desc* d);
+bool conv_wgrad_f32_t16_supported(const codon_conv_desc* d, const void* x, const void* gy);
+int launch_wgrad_f32_t16(const codon_conv_desc* d, const float* x, const float* gy, float* workspace, int nbands,
+                         int nsplit, hipStream_t stream);
+
 struct WgradPlan {
   int co_t, ci_t, nbands, band_tiles_y, nsplit, nchan_blocks;
+  bool t16;
 };
 
 static bool wgrad_plan(const codon_conv_desc* d, WgradPlan* pl) {
@@ -192,9 +199,15 @@ static bool wgrad_plan(const codon_conv_desc* d, WgradPlan* pl) {
   else if (k == 1 && ci == 128 && co == 64) { pl->co_t = 2; pl->ci_t = 2; }
   else return false;
   pl->nchan_blocks = (co / (32 * pl->co_t)) * (ci / (32 * pl->ci_t));
+  // the plan (and with it the workspace size) depends on the descriptor only: shapes the 16x16x4 kernel covers are
+  // planned for its grid (64 cout x 32 cin per workgroup, one workgroup per CU); if the pointers then turn out
+  // misaligned, the round-1 kernel runs on the same band split
+  pl->t16 = conv_wgrad_f32_t16_shape(d);
+  const int plan_blocks = pl->t16 ? (co / 64) * (ci / 32) : pl->nchan_blocks;
+  const int target = pl->t16 ? 768 : 1024;       // workgroups per launch: 3 per CU / 2 x 2 per CU
   const int tiles_y = (d->height + 3) / 4;
-  // enough workgroups to fill 256 CUs x 2, but bounded workspace: bands per image
-  int want = (1024 + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);
+  // enough workgroups to fill the chip, but bounded workspace: bands per image
+  int want = (target + plan_blocks * d->batch - 1) / (plan_blocks * d->batch);
   if (want < 1) want = 1;
   if (want > tiles_y) want = tiles_y;
   pl->band_tiles_y = (tiles_y + want - 1) / want;
@@ -224,6 +237,12 @@ int conv2d_wgrad_f32(const codon_conv_desc* d, const float* x, const float* gy, 
   CODON_REQUIRE(ws_bytes >= conv_wgrad_workspace_bytes(d), CODON_ERR_BAD_ARG,
                 "conv2d_wgrad: workspace %zu B < required %zu B", ws_bytes, conv_wgrad_workspace_bytes(d));
   CODON_REQUIRE(pl.nsplit <= 65535, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: %d splits > 65535", pl.nsplit);
+  static const bool t16_env = getenv("CODON_WGRAD_T16") ? atoi(getenv("CODON_WGRAD_T16")) != 0 : true;   // 0: round-1 kernel (A/B)
+  if (pl.t16 && t16_env && conv_wgrad_f32_t16_supported(d, x, gy)) {
+    const int st = launch_wgrad_f32_t16(d, x, gy, workspace, pl.nbands, pl.nsplit, stream);
+    if (st != CODON_OK) return st;
+    return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
+  }
   const long HW = (long)d->height * d->width;
   WgradParams p;
   p.x = x; p.gy = gy; p.ws = workspace;

@@ -164,7 +164,7 @@ WGRAD_CASES = [(5, 128, 128), (5, 64, 64), (3, 64, 64), (3, 128, 64), (1, 128, 6
 
 
 @pytest.mark.parametrize("k,cin,cout", WGRAD_CASES)
-@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70)])
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 4, 32), (1, 1, 1), (3, 9, 70), (2, 21, 44), (1, 10, 72)])
 def test_conv2d_wgrad_vs_autograd(k, cin, cout, shape):
     from codon_amd import ops
     from codon_amd.ops import Slice
