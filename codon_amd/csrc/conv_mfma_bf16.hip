@@ -86,6 +86,7 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
 //     ahead of their MFMAs, held there by sched_barrier;
 //   * the two channels of a staged word are written as two ds_write_b16 (no v_perm pack, no zero-fill select).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF16_OOB = 0xFFFFFFF0u;
 constexpr int BUF16_FLAGS = 0x00020000;
 
@@ -112,7 +113,7 @@ enum { RES16_NONE = 0, RES16_ADD = 1, RES16_MASK = 2 };
 #define CODON_PSEG3 2
 #endif
 #ifndef CODON_RPS3
-#define CODON_RPS3 3
+#define CODON_RPS3 1
 #endif
 template <int KS, int COUT> struct Conv16Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_PSEG3 : 2; };
 // filter rows per stage: the 3x3 64-cout convs take all three (one barrier per 16-channel chunk, 36 MFMAs per wave
@@ -123,7 +124,12 @@ template <int KS, int COUT> struct Conv16Rps { static constexpr int value = (KS 
 #ifndef CODON_OCC3
 #define CODON_OCC3 2
 #endif
-template <class E, int KS, int CIN, int COUT, bool FUSE = false>
+// XW (W % 4 == 0, 8-byte aligned input slice): the halo tile is fetched with 8-byte loads -- 4 adjacent pixels of one
+// channel plane per lane -- instead of 2-byte ones.  Measured (tools/probes/vmem_issue_probe.hip): a vector-memory
+// instruction costs the CU ~3.4 ns whether a lane fetches 2 or 4 or 8 bytes, and the 64-cout kernels spent as long in
+// 2-byte loads/stores (96 + 64 per wave and tile for 3x3 64->64) as in their MFMAs.  The tile's column origin moves to
+// tx0 - 4 (8-byte aligned; 40 columns staged for the 32 + KS - 1 needed) and a thread owns 4 adjacent 16-byte elements.
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, bool XW = false>
 __global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) void conv_mfma_bf16_kernel(const Conv16Params p) {
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
@@ -131,7 +137,9 @@ __global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) vo
   constexpr int PAD = KS / 2;
   constexpr int PSEG = Conv16Pseg<KS, COUT>::value;
   constexpr int TW = 32, TH = 4 * PSEG;
-  constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
+  constexpr int XLQ = XW ? 4 : PAD;               // columns staged left of the tile
+  constexpr int XR = TH + KS - 1, XQ = XW ? TW + 8 : TW + KS - 1;
+  constexpr int QR = XQ / 4;                      // XW: 4-pixel groups per tile row
   constexpr int CK = 16, NCB = CK / 8;
   constexpr int NCHUNK = CIN / CK;
   constexpr int RPS = Conv16Rps<KS, COUT>::value;   // filter rows per stage
@@ -141,9 +149,10 @@ __global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) vo
   constexpr int WS = RPS * KS * NCB * COUT;     // 16-byte elements per weight stage
   constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * SPC;
-  constexpr int XE = (XS + 255) / 256;    // 16-byte elements (8 channels of a pixel) per thread per chunk
+  constexpr int NQ = NCB * XR * QR;       // XW: 4-element groups per input tile
+  constexpr int XE = XW ? (NQ + 255) / 256 : (XS + 255) / 256;   // staging rounds per chunk (XW: 4 elements per thread and round)
   constexpr int WE = (WS + 255) / 256;
-  constexpr int XSP = XE * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
+  constexpr int XSP = ((XS + 255) / 256) * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
   static_assert(NCHUNK % 2 == 0, "the stage loop is unrolled over chunk pairs");
   static_assert(2 * XSP * 16 < 65536 && 2 * WSP * 16 < 65536, "LDS immediates are 16 bits per region");
 
@@ -176,7 +185,18 @@ __global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) vo
   // resource this kernel is shortest of).  Its 8 channels come from 8 plane loads (wave = 64 consecutive pixels of
   // one plane per instruction) whose plane term is an SGPR.  xoff: byte offset of (plane cb*8, pixel) or out of range.
   unsigned xoff[XE];
-  {
+  if constexpr (XW) {
+    // group e = tid + 256 k = (channel block, row, 4-pixel group); W % 4 == 0: a group is wholly inside or outside
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+      const int e = tid + k * 256;
+      const int cb = e / (XR * QR), rem = e - cb * (XR * QR);
+      const int r = rem / QR, g = rem - r * QR;
+      const int gy = ty0 + r - PAD, gx = tx0 + 4 * g - XLQ;
+      const bool ok = e < NQ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xoff[k] = ok ? (unsigned)(8 * cb) * HW2 + 2u * (unsigned)(gy * W + gx) : BUF16_OOB;
+    }
+  } else {
     constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
     int cb = tid / (XR * XQ);
     int rem = tid - cb * (XR * XQ);
@@ -191,32 +211,52 @@ __global__ __launch_bounds__(256, ((KS == 3 && COUT == 64) ? CODON_OCC3 : 2)) vo
       if (r >= XR) { r -= XR; cb += 1; }
     }
   }
-  const lds_w128 xwr = (lds_w128)(xs0 + tid);
+  const lds_w128 xwr = (lds_w128)(xs0 + (XW ? 4 * tid : tid));
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (WS % 256 == 0 || tid + (WE - 1) * 256 < WS) ? wvo : BUF16_OOB;
   const lds_w128 ww = (lds_w128)(ws0 + tid);
-  const lds_rd xrd = (lds_rd)(xs0 + (half * XR + wave * PSEG) * XQ + l31);
+  const lds_rd xrd = (lds_rd)(xs0 + (half * XR + wave * PSEG) * XQ + l31 + (XLQ - PAD));
   const lds_rd wrd = (lds_rd)(ws0 + half * COUT + l31);
 
   // the next chunk's halo tile is fetched in two halves, during the last two filter rows of the current chunk
   constexpr int XE1 = (KS >= 3 && SPC >= 2) ? XE / 2 : 0, XEH = XE - XE1;
-  u16 xv[XEH][8];
+  u16 xv[XW ? 1 : XEH][8];
+  u32x2 xq[XW ? XEH : 1][8];           // XW: [round][channel] = pixels (0,1) | (2,3) of the lane's 4-pixel group
   u32x4 wr[WE];
 
 #define LOAD_X(chunk_, k0_, k1_)                                                        \
   {                                                                                     \
     const unsigned so_ = (unsigned)(chunk_) * (unsigned)CK * HW2;                       \
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k)                               \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                     \
-        xv[k - (k0_)][j] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, xoff[k], so_ + (unsigned)j * HW2, 0); \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                   \
+        if constexpr (XW) {                                                             \
+          const auto q_ = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, xoff[k], so_ + (unsigned)j * HW2, 0); \
+          xq[k - (k0_)][j] = *reinterpret_cast<const u32x2*>(&q_);                      \
+        } else {                                                                        \
+          xv[k - (k0_)][j] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, xoff[k], so_ + (unsigned)j * HW2, 0); \
+        }                                                                               \
+      }                                                                                 \
   }
 #define STORE_X(buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */            \
   {                                                                                     \
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
-      u32x4 v_;                                                                         \
-      _Pragma("unroll") for (int w = 0; w < 4; ++w)                                     \
-        v_[w] = (unsigned)xv[k - (k0_)][2 * w] | ((unsigned)xv[k - (k0_)][2 * w + 1] << 16); \
-      xwr[(buf_) * XSP + k * 256] = v_;                                                 \
+      if constexpr (XW) {                                                               \
+        if ((NQ % 256 == 0) || k + 1 < XE || tid + k * 256 < NQ) {                      \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {   /* pixel i of the group: channels 2w, 2w+1 -> word w */ \
+            u32x4 v_;                                                                   \
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) {                             \
+              const unsigned a_ = xq[k - (k0_)][2 * w][i >> 1], b_ = xq[k - (k0_)][2 * w + 1][i >> 1]; \
+              v_[w] = (i & 1) ? ((a_ >> 16) | (b_ & 0xffff0000u)) : ((a_ & 0xffffu) | (b_ << 16)); \
+            }                                                                           \
+            xwr[(buf_) * XSP + k * 1024 + i] = v_;                                      \
+          }                                                                             \
+        }                                                                               \
+      } else {                                                                          \
+        u32x4 v_;                                                                       \
+        _Pragma("unroll") for (int w = 0; w < 4; ++w)                                   \
+          v_[w] = (unsigned)xv[k - (k0_)][2 * w] | ((unsigned)xv[k - (k0_)][2 * w + 1] << 16); \
+        xwr[(buf_) * XSP + k * 256] = v_;                                               \
+      }                                                                                 \
     }                                                                                   \
   }
 #define LOAD_W(stage_)                                                                  \
@@ -735,6 +775,15 @@ int pack_chain1x1_16(const float* w, void* out, int dtype, hipStream_t stream) {
   return check_launch("pack_chain1x1_16_kernel");
 }
 
+// 8-byte input loads need W % 4 == 0 (every plane row then starts 8-byte aligned relative to the slice) and an 8-byte
+// aligned slice start; CODON_CONV16_XW=0 forces the 2-byte path (A/B)
+static bool conv16_xwide(const codon_conv_desc* d, const void* x) {
+  static const bool env = getenv("CODON_CONV16_XW") ? atoi(getenv("CODON_CONV16_XW")) != 0 : true;
+  const long HW = (long)d->height * d->width;
+  return env && d->width % 4 == 0 && (reinterpret_cast<uintptr_t>(x) + 2 * (uintptr_t)(d->x_coff * HW)) % 8 == 0 &&
+         (2 * d->x_ctotal * HW) % 8 == 0;
+}
+
 template <class E>
 static int launch_chain16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,
                           const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
@@ -754,7 +803,10 @@ static int launch_chain16(const codon_conv_desc* d, const void* x, const void* w
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  if (conv16_xwide(d, x))
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, true, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, 5, 128, 128, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel<fused 1x1>");
 }
 
@@ -788,7 +840,12 @@ static int launch_conv16(const codon_conv_desc* d, const void* x, const void* w,
   p.dbg = codon_dbg_ptr();
 #endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
-  hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  // 5x5 only: for the 3x3 kernels the 40-column tile costs a resident workgroup (3 instead of 4 per CU) and that costs
+  // more than the narrower loads (A/B same box: 0.965 vs 0.98 ms)
+  if (KS == 5 && conv16_xwide(d, x))
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT, false, (KS == 5)>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<E, KS, CIN, COUT>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_bf16_kernel");
 }
 
