@@ -109,6 +109,31 @@ def cpu_baseline(H, W):
             "config0_1x128x128": {"min_s": c1[0], "median_s": c1[2], "runs": 5}}
 
 
+def config0_gpu_latency(dev):
+    """BASELINE.json configs[0] (1 x 128 x 128 pair, fp32) on the GPU, beside the CPU number for the same case: the
+    reference script's own use (one image per call, test.py:125).  ~95 kernel launches per forward: eager is
+    launch-bound, so the hipGraph replay (codon_amd.graph.GraphedCODON) is reported too."""
+    from codon_amd import CODONNet
+    from codon_amd.graph import GraphedCODON
+    torch.manual_seed(0)
+    m = CODONNet().to(dev).eval()
+    x, y = torch.rand((1, 1, 128, 128), device=dev), torch.rand((1, 1, 128, 128), device=dev)
+    out = {}
+    with torch.no_grad():
+        gm = GraphedCODON(m, x, y)
+        for name, fn in (("eager_ms", lambda: m(x, y)), ("hipgraph_replay_ms", lambda: gm(x, y))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(dev)
+            out[name] = (time.perf_counter() - t0) / 20 * 1e3
+    out["workload"] = "CODON x4 forward, 1 x 128 x 128 pair, fp32 exact (BASELINE.json configs[0]) on 1 MI355X"
+    return out
+
+
 def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype, scale):
     """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP
     dgrad/wgrad/CAC kernels), ONE all-reduce of the flat gradient buffer (RCCL when world > 1), Adam step.
@@ -394,6 +419,8 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)
+            if not bf16 and not split and not rmcr:
+                res["config0_on_gpu"] = config0_gpu_latency(dev)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -6,8 +6,8 @@
 Drop-in module names for the reference's scripts (`from CODON_x4 import CODONNet`) live in
 codon_amd/compat/: put that directory on sys.path.
 """
-from .model import (BaseNet_RMCR_fuseRMCR, BasicConv, CAC_channel, CAC_spatial, ChannelGate, ChannelPool, CODONNet, CODONNet16,
+from .model import (BaseNet_RMCR_fuseRMCR, BaseNet_RMCR_fuseRMCR_cross, BasicConv, CAC_channel, CAC_spatial, ChannelGate, ChannelPool, CODONNet, CODONNet16,
                     Flatten, strip_module_prefix)
 
-__all__ = ["CODONNet", "CODONNet16", "BaseNet_RMCR_fuseRMCR", "CAC_channel", "CAC_spatial", "ChannelGate", "ChannelPool", "BasicConv",
+__all__ = ["CODONNet", "CODONNet16", "BaseNet_RMCR_fuseRMCR", "BaseNet_RMCR_fuseRMCR_cross", "CAC_channel", "CAC_spatial", "ChannelGate", "ChannelPool", "BasicConv",
            "Flatten", "strip_module_prefix"]

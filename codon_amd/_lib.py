@@ -51,6 +51,8 @@ SIGNATURES = {
     "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_cac_stats_tiles": (_I, [_I, _I]),
     "codon_cac_stats_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _I, _P]),
+    "codon_cac_stats_scaled_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _P, _I, _P]),
+    "codon_ew_sq_scale": (C.c_int, [_I, _I, _I, _TP, _P, _TP, _I, _P]),
     "codon_cac_gate_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "codon_cac_spatial_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "codon_stencil_1to64": (C.c_int, [_I, _I, _I, _P, _P, _TP, _I, _TP, _I, _P]),

@@ -33,7 +33,10 @@ template <class P>
 __global__ __launch_bounds__(256) void cac_stats_kernel(const typename P::T* __restrict__ pre_c, long pc_img,
                                                         const typename P::T* __restrict__ pre, long p_img,
                                                         float* __restrict__ pooled, float* __restrict__ partials,
-                                                        long HW, int ntiles) {
+                                                        long HW, int ntiles, const float* __restrict__ chs) {
+  // chs (optional, (B,64)): every value of channel c is multiplied by chs[b][c & 63] first -- the statistics of the
+  // CHANNEL-GATED features, which the sequential-gate ablation feeds to its spatial gate
+  // (CODON_X4/base_net_withoutBN.py:2246-2250)
   __shared__ float red[128][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, b = blockIdx.y;
@@ -50,6 +53,11 @@ __global__ __launch_bounds__(256) void cac_stats_kernel(const typename P::T* __r
     const typename P::T* plane = (c < 64 ? pre_c + b * pc_img + c * HW : pre + b * p_img + (c - 64) * HW);
     float v[8];
     P::load(plane, tile0, tid, HW, v);
+    if (chs) {
+      const float g = chs[b * 64 + (c & 63)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= g;
+    }
     float s = 0.f, m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -216,7 +224,7 @@ static bool aligned16(const void* a, const void* b = nullptr, const void* c = nu
 int cac_stats_tiles(int H, int W) { return (int)(((long)H * W + STATS_TILE - 1) / STATS_TILE); }
 
 int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
-                  float* partials, int dtype, hipStream_t stream) {
+                  float* partials, int dtype, hipStream_t stream, const float* chs) {
   const long HW = (long)H * W;
   const int nt = cac_stats_tiles(H, W);
   CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
@@ -226,7 +234,7 @@ int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tenso
   px_dispatch(dtype, HW, aligned16(pre_c, pre, pooled), [&](auto pol) {
     using P = decltype(pol);
     hipLaunchKernelGGL(cac_stats_kernel<P>, dim3(nt, B), dim3(256), 0, stream, (const typename P::T*)pre_c,
-                       pc->ctotal * HW, (const typename P::T*)pre, pd->ctotal * HW, pooled, partials, HW, nt);
+                       pc->ctotal * HW, (const typename P::T*)pre, pd->ctotal * HW, pooled, partials, HW, nt, chs);
   });
   return check_launch("cac_stats_kernel");
 }
@@ -274,6 +282,41 @@ int cac_apply_fwd(int B, int H, int W, const codon_tensor* pre, const codon_tens
                        mk(pre_c, in_c, out_c), ch, sp, HW);
   });
   return check_launch("cac_apply_kernel");
+}
+
+// y = x * x * ch[b][c]   (64 channels): fuse * ChannelGate(fuse) of the sequential-gate ablation's trunk, where
+// ChannelGate.forward returns x * scale (attention/ResCBAM.py:60-61) and the caller multiplies by x again
+// (CODON_X4/base_net_withoutBN.py:2297-2298).  grid = (tiles, B * 64).
+template <class P>
+__global__ __launch_bounds__(256) void ew_sq_scale_kernel(const typename P::T* __restrict__ x, long x_img,
+                                                          const float* __restrict__ ch, typename P::T* __restrict__ y,
+                                                          long y_img, long HW) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y >> 6, c = blockIdx.y & 63;
+  const long tile0 = (long)blockIdx.x * PX_TILE;
+  const float g = ch[b * 64 + c];
+  float v[8];
+  P::load(x + b * x_img + c * HW, tile0, tid, HW, v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = v[i] * v[i] * g;
+  P::store(y + b * y_img + c * HW, tile0, tid, HW, v);
+}
+
+int ew_sq_scale(int B, int H, int W, const codon_tensor* x, const float* ch, const codon_tensor* y, int dtype,
+                hipStream_t stream) {
+  const long HW = (long)H * W;
+  CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "ew_sq_scale: batch %d too large", B);
+  const size_t es = dtype == CODON_F32 ? 4 : 2;
+  const char* xp = (const char*)x->data + x->coff * HW * es;
+  char* yp = (char*)y->data + y->coff * HW * es;
+  const int nt = (int)((HW + PX_TILE - 1) / PX_TILE);
+  px_dispatch(dtype, HW, aligned16(xp, yp, yp), [&](auto pol) {
+    using P = decltype(pol);
+    using T = typename P::T;
+    hipLaunchKernelGGL(ew_sq_scale_kernel<P>, dim3(nt, B * 64), dim3(256), 0, stream, (const T*)xp, x->ctotal * HW, ch,
+                       (T*)yp, y->ctotal * HW, HW);
+  });
+  return check_launch("ew_sq_scale_kernel");
 }
 
 }  // namespace codon

@@ -66,7 +66,8 @@ int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, co
                 hipStream_t);
 int head_fwd(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
 int cac_stats_tiles(int, int);
-int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t);
+int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t, const float*);
+int ew_sq_scale(int, int, int, const codon_tensor*, const float*, const codon_tensor*, int, hipStream_t);
 int conv2d_fwd_bf16(const codon_conv_desc*, const void*, const void*, void*, const void*, hipStream_t);
 int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int cac_gate_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -269,7 +270,26 @@ int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codo
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_stats_fwd: bad shape");
   CODON_REQUIRE(((uintptr_t)partials % 8) == 0, CODON_ERR_BAD_ARG, "cac_stats_fwd: partials not 8-byte aligned");
   CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_stats_fwd: dtype %d", dtype);
-  return cac_stats_fwd(batch, height, width, pre_c, pre, pooled, partials, dtype, (hipStream_t)stream);
+  return cac_stats_fwd(batch, height, width, pre_c, pre, pooled, partials, dtype, (hipStream_t)stream, nullptr);
+}
+
+int codon_cac_stats_scaled_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre_c,
+                               const codon_tensor* pre, const float* ch, float* pooled, float* partials, int32_t dtype,
+                               codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(pre_c) && slice_ok(pre) && ch && pooled && partials, CODON_ERR_BAD_ARG,
+                "cac_stats_scaled_fwd: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_stats_scaled_fwd: bad shape");
+  CODON_REQUIRE(((uintptr_t)partials % 8) == 0, CODON_ERR_BAD_ARG, "cac_stats_scaled_fwd: partials not 8-byte aligned");
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "cac_stats_scaled_fwd: dtype %d", dtype);
+  return cac_stats_fwd(batch, height, width, pre_c, pre, pooled, partials, dtype, (hipStream_t)stream, ch);
+}
+
+int codon_ew_sq_scale(int32_t batch, int32_t height, int32_t width, const codon_tensor* x, const float* ch,
+                      const codon_tensor* y, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(slice_ok(x) && slice_ok(y) && ch, CODON_ERR_BAD_ARG, "ew_sq_scale: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ew_sq_scale: bad shape");
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "ew_sq_scale: dtype %d", dtype);
+  return ew_sq_scale(batch, height, width, x, ch, y, dtype, (hipStream_t)stream);
 }
 
 int codon_cac_gate_fwd(int32_t batch, int32_t height, int32_t width, const float* partials, const float* w1,

@@ -98,12 +98,13 @@ class _L1SSIMFn(torch.autograd.Function):
         n = p.numel()
         tmp = torch.empty_like(dmaps)
         ga = torch.empty_like(p)
-        gs = float(g)
+        # the kernel is linear in its two scales: run it for an upstream gradient of 1 and scale the 1-channel result by
+        # g ON DEVICE -- float(g) here forced a host synchronisation in every training step
         with torch.cuda.device(dev):
             L.check(lib.codon_ssim_l1_bwd(B, H, W, _p(p), _p(t), _p(dmaps), _p(tmp), _p(ga),
-                                          C.c_float(-gs * w_ssim / n), C.c_float(gs * w_l1 / n), ops._stream(dev)),
+                                          C.c_float(-w_ssim / n), C.c_float(w_l1 / n), ops._stream(dev)),
                     "ssim_l1_bwd")
-        return ga, None, None, None
+        return ga.mul_(g.to(ga.dtype)), None, None, None
 
 
 class L1SSIMLoss(torch.nn.Module):

@@ -427,6 +427,91 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         return out if idt == torch.float32 else out.to(idt)
 
 
+class BaseNet_RMCR_fuseRMCR_cross(_CODONBase):
+    """Sequential-gate ablation: /root/reference/CODON_X4/base_net_withoutBN.py:2186-2317.  Same 49
+    state tensors as CODONNet (here attention_c5 / attention_s5 ARE used); inference only.  Differences from CODONNet:
+      * the spatial gate of a block is computed on the CHANNEL-GATED features (ops.cac_stats_scaled), :2256-2261;
+      * fuse passes through ChannelGate(64) -- whose forward returns x * scale, so the caller's `fuse * gate` squares
+        fuse (ops.ew_sq_scale) -- and a spatial gate, with a residual, before the fusion trunk, :2298-2304.
+    PARITY UNPINNED: the reference file cannot be imported and takes CHANNEL / SPATIAL from a module it does not ship;
+    they are assumed to be CAC_channel / CAC_spatial as in the released CODON_x4.py:5 (oracle.forward_cross, same note)."""
+    _HAS_UNUSED_GATE5 = True
+
+    def forward(self, x, y):
+        if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"expects two (B,1,H,W) tensors, got {tuple(x.shape)} and {tuple(y.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("codon_amd runs on MI355X only (there is no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("BaseNet_RMCR_fuseRMCR_cross: inference only; call under torch.no_grad()")
+        idt = x.dtype
+        x, y = x.float().contiguous(), y.float().contiguous()
+        B, _, H, W = x.shape
+        dev = x.device
+        adt = self._act_dtype()
+        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
+        f32 = lambda t: t if t.dtype == torch.float32 else t.float()
+        fz = dict(dtype=torch.float32, device=dev)
+        P = self._packed
+        S3, S5 = self._split(3), self._split(5)
+        CM = L.PACK_CHAIN1X1_F16X3 if S5 else L.PACK_CHAIN1X1
+        conv = lambda xs, name, ys, k, **kw: ops.conv2d(xs, P(name), ys, k, f16x3=self._split(k), **kw)
+
+        in2, t64, stage, pre2, oc = new(128), new(64), new(128), new(128), new(128)
+        ops.stem(x, f32(self.input.weight), Slice(t64))
+        conv(Slice(t64), "conv_input", Slice(in2, 0, 64), 3, relu=True)
+        ops.stem(y, f32(self.input_c.weight), Slice(t64))
+        conv(Slice(t64), "conv_input_c", Slice(in2, 64, 64), 3, relu=True)
+        nt = ops.cac_stats_tiles(H, W)
+        pooled = torch.empty((B, 2, H, W), **fz)
+        partials = torch.empty((B, nt, 128, 2), **fz)
+        sp = torch.empty((B, 1, H, W), **fz)
+        ch = torch.empty((B, 64), **fz)
+        cur = in2
+        for i in range(5):
+            out, out_c = Slice(cur, 0, 64), Slice(cur, 64, 64)
+            pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
+            conv(out, "conv1", Slice(stage, 0, 64), 3, relu=True)
+            conv(out, "conv2", Slice(stage, 64, 64), 5, relu=True)
+            ops.conv_chain1x1(Slice(stage), P("conv3"), P("confuse", CM), pre, f16x3=S5)
+            conv(out_c, "conv4", Slice(stage, 0, 64), 5, relu=True)
+            conv(out_c, "conv5", Slice(stage, 64, 64), 3, relu=True)
+            ops.conv_chain1x1(Slice(stage), P("conv6"), P("confuse_c", CM), pre_c, f16x3=S5)
+            ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
+            ops.cac_stats(pre_c, pre, pooled, partials)
+            ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                         f32(ac.mlp[3].bias), ch)
+            ops.cac_stats_scaled(pre_c, pre, ch, pooled, partials)      # ChannelPool of the channel-gated features
+            ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
+            ops.cac_apply(pre, pre_c, ch, sp, Slice(in2, 0, 64), Slice(in2, 64, 64), Slice(oc, 0, 64), Slice(oc, 64, 64))
+            cur = oc
+        fuse, fuse2, fuse_g, dump = new(64), new(64), new(64), t64
+        conv(Slice(cur), "conv7", Slice(fuse), 3, relu=True)
+        # ChannelGate(64) = Linear(64,4) / Linear(4,64): run on the 128 -> 8 -> 64 gate kernel with zero-padded weights
+        # over the statistics of (fuse | fuse) -- every padded term is an exact zero
+        g5 = self.attention_c5
+        w1 = torch.zeros((8, 128), **fz); w1[:4, :64] = f32(g5.mlp[1].weight)
+        b1 = torch.zeros((8,), **fz); b1[:4] = f32(g5.mlp[1].bias)
+        w2 = torch.zeros((64, 8), **fz); w2[:, :4] = f32(g5.mlp[3].weight)
+        ops.cac_stats(Slice(fuse), Slice(fuse), pooled, partials)
+        ops.cac_gate(B, H, W, partials, w1, b1, w2, f32(g5.mlp[3].bias), ch)
+        ops.ew_sq_scale(Slice(fuse), ch, Slice(fuse2))                  # fuse * (fuse * scale)
+        ops.cac_stats(Slice(fuse2), Slice(fuse2), pooled, partials)
+        ops.cac_spatial(pooled, f32(self.attention_s5.spatial.conv.weight), sp)
+        ones = torch.ones((B, 64), **fz)
+        ops.cac_apply(Slice(fuse2), Slice(fuse2), ones, sp, Slice(fuse), Slice(fuse), Slice(fuse_g), Slice(dump))
+        f, fA = fuse_g, new(64)
+        for _ in range(3):
+            conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)
+            conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)
+            ops.conv_chain1x1(Slice(stage), P("conv10"), P("confuse_fuse", CM), Slice(fA), residual=Slice(fuse_g), f16x3=S5)
+            f = fA
+        conv(Slice(f), "conv11", Slice(t64), 3, relu=True)
+        out = torch.empty_like(x)
+        ops.head(Slice(t64), f32(self.output.weight), x, out)
+        return out if idt == torch.float32 else out.to(idt)
+
+
 def strip_module_prefix(state_dict):
     """x16 checkpoints are saved from nn.DataParallel (CODON_X16/test.py:52,60): keys carry 'module.'."""
     return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}

@@ -215,6 +215,29 @@ def cac_stats(pre_c: Slice, pre: Slice, pooled: torch.Tensor, partials: torch.Te
                                         _dt(pre.buf), _stream(dev)), "cac_stats_fwd")
 
 
+def cac_stats_scaled(pre_c: Slice, pre: Slice, ch: torch.Tensor, pooled: torch.Tensor, partials: torch.Tensor):
+    """ChannelPool of the channel-gated features (Fcat * ch): the spatial gate's input in the sequential-gate ablation."""
+    lib = L.load()
+    dev = _dev(pre_c.buf, pre.buf, ch, pooled, partials)
+    B, _, H, W = pre.buf.shape
+    assert ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
+    a, b = pre_c.ct(), pre.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_stats_scaled_fwd(B, H, W, C.byref(a), C.byref(b), _ptr(ch), _ptr(pooled), _ptr(partials),
+                                               _dt(pre.buf), _stream(dev)), "cac_stats_scaled_fwd")
+
+
+def ew_sq_scale(x: Slice, ch: torch.Tensor, y: Slice):
+    """y = x * x * ch[b][c] (64-channel slices)."""
+    lib = L.load()
+    dev = _dev(x.buf, ch, y.buf)
+    B, _, H, W = x.buf.shape
+    assert x.c == 64 and y.c == 64 and ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
+    xt, yt = x.ct(), y.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_ew_sq_scale(B, H, W, C.byref(xt), _ptr(ch), C.byref(yt), _dt(x.buf), _stream(dev)), "ew_sq_scale")
+
+
 def cac_gate(B: int, H: int, W: int, partials, w1, b1, w2, b2, ch, pools_out=None):
     lib = L.load()
     dev = _dev(partials, w1, b1, w2, b2, ch, pools_out)

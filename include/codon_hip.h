@@ -160,6 +160,16 @@ int32_t codon_cac_stats_tiles(int32_t height, int32_t width);
 int codon_cac_stats_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre_c,
                         const codon_tensor* pre, float* pooled, float* partials, int32_t dtype,
                         codon_stream_t stream);
+/* Sequential-gate ablation (BaseNet_RMCR_fuseRMCR_cross, /root/reference/CODON_X4/base_net_withoutBN.py:2186-2317; SURVEY.md
+ * 8f row f4): its spatial gate sees the CHANNEL-GATED features, and its trunk squares the 64-channel fuse tensor
+ * through ChannelGate's `x * scale` return value.
+ *   cac_stats_scaled_fwd: codon_cac_stats_fwd on Fcat[b][c] * ch[b][c & 63]  (ch: (B,64) fp32; only `pooled` is meaningful)
+ *   ew_sq_scale         : y = x * x * ch[b][c] over a 64-channel slice */
+int codon_cac_stats_scaled_fwd(int32_t batch, int32_t height, int32_t width, const codon_tensor* pre_c,
+                               const codon_tensor* pre, const float* ch, float* pooled, float* partials,
+                               int32_t dtype, codon_stream_t stream);
+int codon_ew_sq_scale(int32_t batch, int32_t height, int32_t width, const codon_tensor* x, const float* ch,
+                      const codon_tensor* y, int32_t dtype, codon_stream_t stream);
 int codon_cac_gate_fwd(int32_t batch, int32_t height, int32_t width, const float* partials,
                        const float* w1, const float* b1, const float* w2, const float* b2,
                        float* ch, float* pools_out, codon_stream_t stream);

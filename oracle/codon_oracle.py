@@ -233,6 +233,49 @@ def forward_rmcr(sd, x, y):
     return _conv(r(_conv(f, w("conv11"))), w("output")) + x
 
 
+def forward_cross(sd, x, y):
+    """BaseNet_RMCR_fuseRMCR_cross.forward, /root/reference/CODON_X4/base_net_withoutBN.py:2234-2317 -- the sequential
+    gate ablation: channel gate first, spatial gate computed on the channel-gated features, and a gated fusion trunk.
+
+    PARITY UNPINNED, twice over: the file is un-importable, and it takes CHANNEL / SPATIAL from a module
+    `wechat_guide` that the reference does not ship (:16-17).  This restatement ASSUMES they are the classes the released
+    CODON_x4.py imports under the same aliases (`from CAC_module import CAC_channel as CHANNEL, CAC_spatial as SPATIAL`,
+    CODON_x4.py:5): both return the gate only.  attention_c5 is attention/ResCBAM.py's ChannelGate, whose forward returns
+    x * scale (:60-61) -- so `fuse * attention_c_fuse` (:2298) squares fuse; attention_s5 is SPATIAL (gate only)."""
+    r = F.relu
+    w = lambda k: sd[k + ".weight"]
+    inputs = r(_conv(r(_conv(x, w("input"))), w("conv_input")))          # :2236-2237
+    inputs_c = r(_conv(r(_conv(y, w("input_c"))), w("conv_input_c")))    # :2239-2240
+    out, out_c = inputs, inputs_c
+    for i in range(5):
+        stage = torch.cat((r(_conv(out, w("conv1"))), r(_conv(out, w("conv2")))), 1)          # :2243,2245,2247
+        stage_c = torch.cat((r(_conv(out_c, w("conv4"))), r(_conv(out_c, w("conv5")))), 1)    # :2244,2246,2248
+        out_c = _conv(r(_conv(stage_c, w("conv6"))), w("confuse_c"))     # :2250-2251
+        out = _conv(r(_conv(stage, w("conv3"))), w("confuse"))           # :2249,2252
+        att_cat = torch.cat((out_c, out), 1)                             # :2253
+        ch = cac_channel(att_cat, sd[f"attention_c{i}.mlp.1.weight"], sd[f"attention_c{i}.mlp.1.bias"],
+                         sd[f"attention_c{i}.mlp.3.weight"], sd[f"attention_c{i}.mlp.3.bias"])[:, :, None, None]
+        out_c, out = out_c * ch, out * ch                                # :2256-2257
+        sp = cac_spatial(torch.cat((out_c, out), 1), sd[f"attention_s{i}.spatial.conv.weight"])   # :2258-2259
+        out_c = out_c * sp + inputs_c                                    # :2260, :2295
+        out = out * sp + inputs                                          # :2261, :2296
+    fuse = r(_conv(torch.cat((out, out_c), 1), w("conv7")))              # :2298-2299
+    res_fuse = fuse
+    H, W = fuse.shape[2], fuse.shape[3]
+    avg = F.avg_pool2d(fuse, (H, W), stride=(H, W)).flatten(1)
+    mx = F.max_pool2d(fuse, (H, W), stride=(H, W)).flatten(1)
+    mlp5 = lambda v: F.linear(F.relu(F.linear(v, sd["attention_c5.mlp.1.weight"], sd["attention_c5.mlp.1.bias"])),
+                              sd["attention_c5.mlp.3.weight"], sd["attention_c5.mlp.3.bias"])
+    att_c = fuse * torch.sigmoid(mlp5(avg) + mlp5(mx))[:, :, None, None]   # :2301  (ChannelGate returns x * scale)
+    fuse = fuse * att_c                                                  # :2302
+    fuse = fuse * cac_spatial(fuse, sd["attention_s5.spatial.conv.weight"]) + res_fuse   # :2303-2304
+    f = fuse
+    for _ in range(3):                                                   # :2306-2312
+        st = torch.cat((r(_conv(f, w("conv8"))), r(_conv(f, w("conv9")))), 1)
+        f = _conv(r(_conv(st, w("conv10"))), w("confuse_fuse")) + fuse
+    return _conv(r(_conv(f, w("conv11"))), w("output")) + x             # :2313-2315
+
+
 def forward_numpy(sd, x, y):
     with torch.no_grad():
         return forward(sd, torch.as_tensor(x), torch.as_tensor(y)).numpy()
