@@ -99,12 +99,16 @@ def cpu_baseline(H, W):
             t0 = time.perf_counter()
             orc.forward(sd, x1, y1)
             c1.append(time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        orc.forward(sd, x, y)
-        dt = time.perf_counter() - t0
+        full = []
+        for _ in range(3):                       # ~6 s each on 16 threads: bounded at ~20 s
+            t0 = time.perf_counter()
+            orc.forward(sd, x, y)
+            full.append(time.perf_counter() - t0)
     c1.sort()
+    full.sort()
+    dt = full[1]
     return {"value": 1.0 / dt, "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image (1x1x{H}x{W} pair) of the batch, one oracle forward, {dt:.1f} s",
+            "sample": f"1 image (1x1x{H}x{W} pair) of the batch, 3 oracle forwards: median {dt:.1f} s, min {full[0]:.1f} s",
             "mpx_per_s": H * W / dt / 1e6,
             "config0_1x128x128": {"min_s": c1[0], "median_s": c1[2], "runs": 5}}
 

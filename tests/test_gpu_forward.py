@@ -70,6 +70,28 @@ def test_forward_matches_oracle_random(shape, seed):
     assert rel_rmse(o.cpu(), ref) <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 370, 463), (1, 375, 450), (1, 247, 343)])
+def test_forward_at_the_reference_scripts_image_sizes(shape):
+    """The images the reference script actually feeds (Middlebury crops under CODON_X*/input_depth: odd widths, one
+    image per call, test.py:116-125): fp32 vs the oracle at the 1e-4 bar, and the script's own precision (.half())
+    against the same oracle at the fp16 tolerance."""
+    B, H, W = shape
+    sd = orc.he_state("x4", seed=70 + H)
+    g = np.random.default_rng(H)
+    x = torch.from_numpy(g.random((B, 1, H, W), dtype=np.float32))
+    y = torch.from_numpy((g.integers(0, 256, size=(B, 1, H, W)) / 255.0).astype(np.float32))
+    with torch.no_grad():
+        ref = orc.forward(sd, x, y)
+    m = _model("x4", sd)
+    with torch.no_grad():
+        o = m(x.cuda(), y.cuda())
+    assert rmse(o.cpu(), ref) <= RMSE_TOL and rel_rmse(o.cpu(), ref) <= 2e-5
+    mh = _model("x4", sd).half()
+    with torch.no_grad():
+        oh = mh(x.cuda().half(), y.cuda().half())
+    assert rel_rmse(oh.float().cpu(), ref) <= 6e-3
+
+
 def test_batch_independence_and_determinism():
     """Images are independent units (no op mixes samples): a batch equals its images
     run one by one, bit for bit; and two runs are bit-identical (fixed-order reductions)."""
