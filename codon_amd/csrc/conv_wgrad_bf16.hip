@@ -307,7 +307,7 @@ int launch_wgrad_cm16(const codon_conv_desc* d, const void* x, const void* gy, f
                       int band_tiles_y, int nbands, int nsplit, int nchan_blocks, hipStream_t stream);
 
 #ifndef CODON_WGRAD16_TARGET
-#define CODON_WGRAD16_TARGET 512
+#define CODON_WGRAD16_TARGET 256
 #endif
 constexpr int WGRAD16_TARGET_BLOCKS = CODON_WGRAD16_TARGET;   // workgroups per launch the band split aims for
 
