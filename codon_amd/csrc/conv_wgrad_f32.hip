@@ -203,7 +203,7 @@ static bool wgrad_plan(const codon_conv_desc* d, WgradPlan* pl) {
   // planned for its grid (64 cout x 32 cin per workgroup, one workgroup per CU); if the pointers then turn out
   // misaligned, the round-1 kernel runs on the same band split
   pl->t16 = conv_wgrad_f32_t16_shape(d);
-  const int plan_blocks = pl->t16 ? (co / 64) * (ci / 32) : pl->nchan_blocks;
+  const int plan_blocks = pl->t16 ? (co / 64) * (ci / (k == 1 ? 128 : 32)) : pl->nchan_blocks;
 #ifndef CODON_WGRAD32_TARGET
 #define CODON_WGRAD32_TARGET 256
 #endif

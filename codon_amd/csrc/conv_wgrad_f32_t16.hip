@@ -18,7 +18,7 @@
 //   * staging is a straight copy of 16-byte row chunks (buffer loads, tile origin in the descriptor base, offsets
 //     hoisted, out-of-image chunks out of range), written with ds_write_b64; the next tile is requested before the
 //     current tile's MFMAs and written after them; one barrier per tile.
-// Needs W % 4 == 0 and 16-byte aligned slices (the launcher falls back to conv_wgrad_f32.hip otherwise); k in {3, 5}.
+// Needs W % 4 == 0 and 16-byte aligned slices (the launcher falls back to conv_wgrad_f32.hip otherwise); k in {1, 3, 5}.
 // Partials -> workspace[split][tap][co][ci], summed in fixed order by wgrad_reduce_kernel: deterministic.
 
 #include <type_traits>
@@ -49,17 +49,23 @@ struct WgradT16Params {
   int tiles_x, nbands, nsplit;
 };
 
+// k = 1 (confuse*: HBM-bound -- 768 B per pixel for 16 K MACs): the workgroup covers ALL 128 cin (4 cin tiles per wave,
+// waves = 4 cout tiles x 2 cin halves) so gy is read once, not once per 32-cin block, in 2-row tiles (double-buffered
+// 101 KB).  Round 1's kernel moved 2 x the bytes single-buffered: 24 TF = 1.15 TB/s.
 template <int KS>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT16Params p) {
   constexpr int PAD = KS / 2, TAPS = KS * KS;
-  constexpr int TW = 32, TH = 4;
-  constexpr int XL = 4;                          // left / right margin: the tile's column origin tx0 - 4 is 16-byte aligned
+  constexpr int NCIT = KS == 1 ? 4 : 1;          // 16-cin tiles per wave
+  constexpr int NCI = 32 * NCIT;                 // cin per workgroup
+  constexpr int NACC = TAPS * NCIT;
+  constexpr int TW = 32, TH = KS == 1 ? 2 : 4;
+  constexpr int XL = KS == 1 ? 0 : 4;            // left / right margin: the tile's column origin tx0 - 4 is 16-byte aligned
   constexpr int XC = TW + 2 * XL, XR = TH + KS - 1;
   constexpr int XPL = ((XR * XC + 29) / 32) * 32 + 2;   // words per channel plane, == 2 (mod 32), >= XR * XC
-  constexpr int GPL = TH * TW + 2;                      // 130 == 2 (mod 32)
+  constexpr int GPL = TH * TW + 2;                      // == 2 (mod 32)
   static_assert(XPL >= XR * XC && XPL % 32 == 2 && GPL % 32 == 2, "plane strides");
-  constexpr int XW = 32 * XPL, GW = 64 * GPL;    // words per buffer
-  constexpr int NXC = 32 * XR * (XC / 4), NGC = 64 * TH * (TW / 4);   // 16-byte chunks per tile
+  constexpr int XW = NCI * XPL, GW = 64 * GPL;   // words per buffer
+  constexpr int NXC = NCI * XR * (XC / 4), NGC = 64 * TH * (TW / 4);   // 16-byte chunks per tile
   constexpr int NT = 512;
   constexpr int XE = (NXC + NT - 1) / NT, GE = NGC / NT;
   static_assert(NGC % NT == 0, "gy tile is a whole number of staging rounds");
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
   const long HW = (long)H * W;
   const unsigned HW4 = 4u * (unsigned)H * (unsigned)W;
 
-  const int nci_b = p.cin / 32;
+  const int nci_b = p.cin / NCI;
   // workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest): left alone, the channel blocks that
   // read the SAME image band (same blockIdx.y) land on 8 different XCDs and each L2 fetches the band again.  The bijective
   // remap gives every XCD a contiguous range of (band, channel block) pairs, so a band's channel blocks share one L2.
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
   const int ty_end = (int)((long)(band + 1) * tiles_y / p.nbands);
   const int ntile = (ty_end - ty_begin) * p.tiles_x;
 
-  const float* const xg = p.x + b * p.x_img + p.x_base + (long)cib * 32 * HW;
+  const float* const xg = p.x + b * p.x_img + p.x_base + (long)cib * NCI * HW;
   const float* const gg = p.gy + b * p.g_img + p.g_base + (long)cob * 64 * HW;
 
   // staging plan (tile independent): chunk e = tid + NT k -> (channel, row, 4-pixel column chunk)
@@ -112,13 +118,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
     glds[k] = c * GPL + r * TW + ch * 4;
   }
 
-  const int co16 = wave & 3, ci16 = wave >> 2;
+  const int co16 = wave & 3, ci16 = wave >> 2;            // k = 1: ci16 = which 64-cin half
   const int a_lane = (co16 * 16 + l15) * GPL + kq;
-  const int b_lane = (ci16 * 16 + l15) * XPL + kq + (XL - PAD);
+  const int b_lane = (ci16 * 16 * NCIT + l15) * XPL + kq + (XL - PAD);
 
-  f32x4 acc[TAPS];
+  f32x4 acc[NACC];
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j)
+  for (int j = 0; j < NACC; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
 
@@ -179,13 +185,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
     // K loop: 4 horizontally adjacent pixels per MFMA; every fragment address is `lane base + immediate`.  The
     // fragments of k-step s + 1 (1 + KS*KS volatile ds_read_b32, issued back to back) are requested before the KS*KS
     // MFMAs of k-step s; sched_barrier keeps that order (left alone, hipcc hoists hundreds of reads and spills).
-    float a[2], bv[2][TAPS];
+    float a[2], bv[2][NACC];
 #define T16_FETCH(set_, r_, q_)                                                           \
     {                                                                                     \
       a[set_] = ap[(r_) * TW + (q_)];                                                     \
-      _Pragma("unroll") for (int dy = 0; dy < KS; ++dy)                                   \
-        _Pragma("unroll") for (int dx = 0; dx < KS; ++dx)                                 \
-          bv[set_][dy * KS + dx] = bp[((r_) + dy) * XC + (q_) + dx];                      \
+      _Pragma("unroll") for (int ct = 0; ct < NCIT; ++ct)                                 \
+        _Pragma("unroll") for (int dy = 0; dy < KS; ++dy)                                 \
+          _Pragma("unroll") for (int dx = 0; dx < KS; ++dx)                               \
+            bv[set_][ct * TAPS + dy * KS + dx] = bp[ct * 16 * XPL + ((r_) + dy) * XC + (q_) + dx]; \
     }
     T16_FETCH(0, 0, 0)
     t16_static_for<TH * (TW / 4)>([&](auto sc) {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
       if constexpr (s_ + 1 < TH * (TW / 4)) T16_FETCH(cur ^ 1, (s_ + 1) / (TW / 4), ((s_ + 1) % (TW / 4)) * 4)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < TAPS; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur], bv[cur][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur], bv[cur][j], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
 #undef T16_FETCH
@@ -204,19 +211,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f32_t16_kernel(const WgradT
 
   // partial dW -> workspace[split][tap][co][ci]: lane = ci column, 4 consecutive co rows in registers
   float* __restrict__ wsp = p.ws + (long)split * TAPS * p.cout * p.cin;
-  const int ci = cib * 32 + ci16 * 16 + l15;
 #pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap)
+  for (int ct = 0; ct < NCIT; ++ct) {
+    const int ci = cib * NCI + (ci16 * NCIT + ct) * 16 + l15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cob * 64 + co16 * 16 + 4 * kq + r;
-      wsp[((long)tap * p.cout + co) * p.cin + ci] = acc[tap][r];
-    }
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cob * 64 + co16 * 16 + 4 * kq + r;
+        wsp[((long)tap * p.cout + co) * p.cin + ci] = acc[ct * TAPS + tap][r];
+      }
+  }
 }
 
 bool conv_wgrad_f32_t16_shape(const codon_conv_desc* d) {
-  return (d->ksize == 3 || d->ksize == 5) && d->width % 4 == 0 && d->cout % 64 == 0 && d->cin % 32 == 0 &&
-         (long)d->height * d->width * 4 * 64 < 0xFFFFFFF0L;          // 32-bit chunk offsets: up to 64 planes of a slice
+  if (d->ksize == 1 && d->cin % 128 != 0) return false;
+  return (d->ksize == 1 || d->ksize == 3 || d->ksize == 5) && d->width % 4 == 0 && d->cout % 64 == 0 && d->cin % 32 == 0 &&
+         (long)d->height * d->width * 4 * 128 < 0xFFFFFFF0L;         // 32-bit chunk offsets: up to 128 planes of a slice
 }
 
 bool conv_wgrad_f32_t16_supported(const codon_conv_desc* d, const void* x, const void* gy) {
@@ -237,9 +248,10 @@ int launch_wgrad_f32_t16(const codon_conv_desc* d, const float* x, const float* 
   p.x_img = d->x_ctotal * HW; p.g_img = d->y_ctotal * HW;
   p.x_base = d->x_coff * HW; p.g_base = d->y_coff * HW;
   p.tiles_x = (d->width + 31) / 32; p.nbands = nbands; p.nsplit = nsplit;
-  const dim3 grid((d->cout / 64) * (d->cin / 32), nsplit);
+  const dim3 grid((d->cout / 64) * (d->cin / (d->ksize == 1 ? 128 : 32)), nsplit);
   if (d->ksize == 5) hipLaunchKernelGGL(conv_wgrad_f32_t16_kernel<5>, grid, dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL(conv_wgrad_f32_t16_kernel<3>, grid, dim3(512), 0, stream, p);
+  else if (d->ksize == 3) hipLaunchKernelGGL(conv_wgrad_f32_t16_kernel<3>, grid, dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_f32_t16_kernel<1>, grid, dim3(512), 0, stream, p);
   return check_launch("conv_wgrad_f32_t16_kernel");
 }
 
