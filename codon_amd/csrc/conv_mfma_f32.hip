@@ -460,9 +460,18 @@ int pack_chain1x1_f32(const float* w, float* out, hipStream_t stream) {
   return check_launch("pack_chain1x1_f32_kernel");
 }
 
+// SMALL-GRID MODE.  A launch whose 8 x 32 tiling gives fewer workgroups than ~1.5 per CU (single images: the reference
+// script's own use, test.py:125, and BASELINE configs[0]) is latency-bound on one workgroup's K loop; it takes 4 x 32
+// tiles instead (PSEG = 1: twice the workgroups, half the MFMAs each).  Per-pixel arithmetic and its order are the
+// same, so results stay bit-identical to the large-grid kernels (batch-independence tests compare the two).
+constexpr long SMALL_GRID = 384;
+static bool small_grid(const codon_conv_desc* d) {
+  return (long)((d->width + 31) / 32) * ((d->height + 7) / 8) * d->batch < SMALL_GRID;
+}
+
 template <int KS, int CIN, int COUT, int PSEG>
-static int launch_conv(const codon_conv_desc* d, const float* x, const float* w, float* y,
-                       const float* res, hipStream_t stream) {
+static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* w, float* y,
+                         const float* res, hipStream_t stream) {
   constexpr int TH = 4 * PSEG;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res;
@@ -487,12 +496,19 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   return check_launch("conv_mfma_f32_kernel");
 }
 
+template <int KS, int CIN, int COUT, int PSEG>
+static int launch_conv(const codon_conv_desc* d, const float* x, const float* w, float* y,
+                       const float* res, hipStream_t stream) {
+  if (small_grid(d)) return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, stream);
+  return launch_conv_p<KS, CIN, COUT, PSEG>(d, x, w, y, res, stream);
+}
+
 int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
 
-template <int KS, int CIN, int COUT>
-static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
-                        const float* sp, const float* w, float* y, hipStream_t stream) {
-  constexpr int TH = 8;
+template <int KS, int CIN, int COUT, int PSEG>
+static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
+                          const float* sp, const float* w, float* y, hipStream_t stream) {
+  constexpr int TH = 4 * PSEG;
   ConvParams p;
   p.x = pre; p.w = w; p.y = y; p.res = nullptr;
   p.H = d->height; p.W = d->width;
@@ -513,8 +529,15 @@ static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, 2, false, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel<gated>");
+}
+
+template <int KS, int CIN, int COUT>
+static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
+                        const float* sp, const float* w, float* y, hipStream_t stream) {
+  if (small_grid(d)) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, stream);
+  return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, stream);
 }
 
 int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
@@ -538,7 +561,9 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
                           const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
-  constexpr int NWC = CODON_CHAIN_NW, TH = 2 * NWC;
+  constexpr int NWC = CODON_CHAIN_NW;
+  const bool small = small_grid(d);
+  const int TH = (small ? 1 : 2) * NWC;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res ? (const float*)res->data : nullptr;
   p.H = d->height; p.W = d->width;
@@ -558,7 +583,10 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
+  if (small)
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");
 }
 
