@@ -88,3 +88,36 @@ def test_flat_views_and_single_process_noop():
     assert gs.all_reduce_grads() is None               # no process group: nothing to do
     gs.zero_grad()
     assert float(gs.flat.abs().sum()) == 0.0
+
+
+def test_grad_views_survive_set_to_none():
+    """ADVICE r1: optimizer.zero_grad() defaults to set_to_none=True, which drops the .grad views into the flat buffer;
+    the next all_reduce_grads() (or gs.zero_grad()) must adopt whatever gradients exist and re-install the views, so the
+    collective never reduces stale zeros."""
+    from codon_amd import CODONNet16
+    from codon_amd.dist import GradSync
+    m = CODONNet16()
+    gs = GradSync(m)
+    opt = torch.optim.SGD(gs.params, lr=0.1)
+    opt.zero_grad()                                     # set_to_none=True: every .grad is None now
+    assert m.conv3.weight.grad is None
+    m.conv3.weight.grad = torch.full_like(m.conv3.weight, 3.0)       # a gradient produced OUTSIDE the buffer
+    m.confuse.weight.grad = torch.full_like(m.confuse.weight, 1.0)
+    gs.all_reduce_grads()                               # single process: no collective, but the views are repaired
+    assert m.conv3.weight.grad._base is gs.flat and m.input.weight.grad._base is gs.flat
+    assert float(gs.flat.sum()) == 3.0 * m.conv3.weight.numel() + m.confuse.weight.numel()
+    gs.zero_grad()
+    assert float(gs.flat.abs().sum()) == 0.0 and m.conv3.weight.grad._base is gs.flat
+
+
+def test_broadcast_invalidates_packed_weights():
+    """GradSync.broadcast_parameters must drop packed conv weights (single process: the no-op path leaves them)."""
+    from codon_amd import CODONNet16
+    from codon_amd.dist import GradSync
+    m = CODONNet16()
+    gs = GradSync(m)
+    m._pack_cache["probe"] = ("tag", torch.zeros(1))
+    gs.broadcast_parameters(0)                          # no process group -> returns early, cache untouched
+    assert "probe" in m._pack_cache
+    m.invalidate_packed()
+    assert not m._pack_cache

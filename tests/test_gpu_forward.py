@@ -219,3 +219,10 @@ def test_hipgraph_replay_equals_eager():
         with torch.no_grad():
             ref = m(x, y)
         assert torch.equal(gm(x, y), ref)
+    # a weight update after capture is refused, not replayed on stale packed weights
+    assert not gm.stale()
+    with torch.no_grad():
+        m.conv3.weight.mul_(1.0)          # in-place, autograd-visible: bumps Tensor._version
+    assert gm.stale()
+    with pytest.raises(RuntimeError, match="changed after capture"):
+        gm(x, y)
