@@ -68,7 +68,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     B, _, H, W = x.shape
     dev = x.device
     adt = model._act_dtype()                       # activation-gradient dtype follows the activations
-    new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
+    new = lambda c: ops.new_act(B, c, H, W, adt, dev)
     f32 = lambda t: t if t.dtype == torch.float32 else t.float()
     gy = f32(gy)
     G = {}                                         # parameter gradients: always fp32

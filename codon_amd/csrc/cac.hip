@@ -216,6 +216,12 @@ __global__ __launch_bounds__(256) void cac_apply_kernel(const ApplyStream<typena
   P::store(s.out + b * s.out_img + c * HW, tile0, tid, HW, v);
 }
 
+// ew_c8.hip: the same passes over channel-blocked 16-bit tensors
+int cac_stats_fwd_c8(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t, const float*);
+int cac_apply_fwd_c8(int, int, int, const codon_tensor*, const codon_tensor*, const float*, const float*, const codon_tensor*,
+                     const codon_tensor*, const codon_tensor*, const codon_tensor*, int, hipStream_t);
+int ew_sq_scale_c8(int, int, int, const codon_tensor*, const float*, const codon_tensor*, int, hipStream_t);
+
 static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d)) % 16) == 0;
@@ -225,10 +231,11 @@ int cac_stats_tiles(int H, int W) { return (int)(((long)H * W + STATS_TILE - 1) 
 
 int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
                   float* partials, int dtype, hipStream_t stream, const float* chs) {
+  if (dtype != CODON_F32) return cac_stats_fwd_c8(B, H, W, pc, pd, pooled, partials, dtype, stream, chs);
   const long HW = (long)H * W;
   const int nt = cac_stats_tiles(H, W);
   CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
-  const size_t es = dtype == CODON_F32 ? 4 : 2;
+  const size_t es = 4;
   const char* pre_c = (const char*)pc->data + pc->coff * HW * es;
   const char* pre = (const char*)pd->data + pd->coff * HW * es;
   px_dispatch(dtype, HW, aligned16(pre_c, pre, pooled), [&](auto pol) {
@@ -262,9 +269,10 @@ int cac_spatial_fwd(int B, int H, int W, const float* pooled, const float* w, fl
 int cac_apply_fwd(int B, int H, int W, const codon_tensor* pre, const codon_tensor* pre_c, const float* ch,
                   const float* sp, const codon_tensor* in, const codon_tensor* in_c, const codon_tensor* out,
                   const codon_tensor* out_c, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32) return cac_apply_fwd_c8(B, H, W, pre, pre_c, ch, sp, in, in_c, out, out_c, dtype, stream);
   const long HW = (long)H * W;
   CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "cac_apply_fwd: batch %d too large", B);
-  const size_t es = dtype == CODON_F32 ? 4 : 2;
+  const size_t es = 4;
   auto base = [&](const codon_tensor* t) { return (char*)t->data + t->coff * HW * es; };
   const bool al = aligned16(base(pre), base(in), base(out), sp) && aligned16(base(pre_c), base(in_c), base(out_c));
   const unsigned nt = (unsigned)((HW + PX_TILE - 1) / PX_TILE);
@@ -304,9 +312,10 @@ __global__ __launch_bounds__(256) void ew_sq_scale_kernel(const typename P::T* _
 
 int ew_sq_scale(int B, int H, int W, const codon_tensor* x, const float* ch, const codon_tensor* y, int dtype,
                 hipStream_t stream) {
+  if (dtype != CODON_F32) return ew_sq_scale_c8(B, H, W, x, ch, y, dtype, stream);
   const long HW = (long)H * W;
   CODON_REQUIRE((long)B * 64 <= 65535, CODON_ERR_UNSUPPORTED, "ew_sq_scale: batch %d too large", B);
-  const size_t es = dtype == CODON_F32 ? 4 : 2;
+  const size_t es = 4;
   const char* xp = (const char*)x->data + x->coff * HW * es;
   char* yp = (char*)y->data + y->coff * HW * es;
   const int nt = (int)((HW + PX_TILE - 1) / PX_TILE);

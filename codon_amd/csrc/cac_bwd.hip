@@ -347,6 +347,13 @@ __global__ __launch_bounds__(256) void ew_add_mask_kernel(typename P::T* __restr
 }
 
 // ---- host ------------------------------------------------------------------------------------------
+// ew_c8.hip: passes A and D and the elementwise helper over channel-blocked 16-bit tensors
+int cac_bwd_reduce_c8(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
+                      const float*, const float*, const float*, float*, float*, int*, int, hipStream_t);
+int cac_bwd_apply_c8(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
+                     const float*, const float*, const float*, const float*, const float*, const int*, const codon_tensor*,
+                     const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int, hipStream_t);
+int ew_add_mask_c8(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int, hipStream_t);
 static bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d)) % 16) == 0;
@@ -356,7 +363,7 @@ static Sl<T> mk(const codon_tensor* t, long HW) { return Sl<T>{(const T*)t->data
 template <class T>
 static SlW<T> mkw(const codon_tensor* t, long HW) { return SlW<T>{(T*)t->data + t->coff * HW, t->ctotal * HW}; }
 static const char* basep(const codon_tensor* t, long HW, int dtype) {
-  return (const char*)t->data + t->coff * HW * (dtype == CODON_F32 ? 4 : 2);
+  return (const char*)t->data + t->coff * HW * 4;
 }
 
 int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }
@@ -365,6 +372,8 @@ int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W 
 int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
                    const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
                    const float* pools, float* g_z, float* part_gch, int* part_arg, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32)
+    return cac_bwd_reduce_c8(B, H, W, g_out, g_outc, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg, dtype, stream);
   const long HW = (long)H * W;
   const int nt = cac_bwd_tiles(H, W);
   const bool al = al16(basep(g_out, HW, dtype), basep(g_outc, HW, dtype), basep(pre, HW, dtype),
@@ -425,6 +434,9 @@ int cac_bwd_apply(int B, int H, int W, const codon_tensor* g_out, const codon_te
                   const float* pooled, const float* g_pooled, const float* g_pools, const int* argpix,
                   const codon_tensor* g_pre, const codon_tensor* g_pre_c, const codon_tensor* g_in,
                   const codon_tensor* g_in_c, int accumulate_in, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32)
+    return cac_bwd_apply_c8(B, H, W, g_out, g_outc, pre, pre_c, ch, sp, pooled, g_pooled, g_pools, argpix, g_pre, g_pre_c,
+                            g_in, g_in_c, accumulate_in, dtype, stream);
   const long HW = (long)H * W;
   const int nt = cac_bwd_tiles(H, W);
   const float inv = (float)(1.0 / (double)HW);
@@ -445,6 +457,7 @@ int cac_bwd_apply(int B, int H, int W, const codon_tensor* g_out, const codon_te
 
 int ew_add_mask(int B, int H, int W, int C, const codon_tensor* dst, const codon_tensor* src,
                 const codon_tensor* mask, int accumulate, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32) return ew_add_mask_c8(B, H, W, C, dst, src, mask, accumulate, dtype, stream);
   const long HW = (long)H * W;
   CODON_REQUIRE((long)B * C <= 65535, CODON_ERR_UNSUPPORTED, "ew_add_mask: batch*channels too large");
   const char* d = basep(dst, HW, dtype);

@@ -1,0 +1,668 @@
+// 16-bit (bf16 / fp16) implicit-GEMM convolution on the gfx950 matrix cores over CHANNEL-BLOCKED activations (c8.h):
+// v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate.  The conv is nn.Conv2d stride 1 / pad k//2 / no bias of
+// /root/reference/CODON_X4/CODON_x4.py:24-47; BASELINE.json configs[2] and [4], and the reference script's own .half().
+//
+// Operand roles as in the fp32 kernel (conv_mfma_f32.hip): A = weights -> cout rows, B = activations -> pixel columns,
+// so a 32x32 result tile has one pixel column per lane and 16 cout rows in registers.  K per MFMA = 16 input channels,
+// 8 consecutive ones per lane -- which is exactly one 16-byte vector of the C8 layout:
+//   xs[cb][row][col] : halo tile of one 16-channel chunk, 16-byte elements; staged by straight 16-byte copies
+//                      (one buffer_load_b128 + one conflict-free ds_write_b128 per element: the LDS index IS the
+//                      thread's element number); a half-wave's B fragment = 32 consecutive elements of a tile row
+//   ws[dx][cb][cout] : 16-byte elements = 8 input channels of one (tap, cout); the packer puts cout
+//                      tile*32 + swap23(i) in row i of every 32-row tile, so accumulator registers 8g..8g+7 of lane
+//                      half h are the 8 channels of output plane tile*4 + 2g + h: the epilogue converts them pairwise
+//                      and writes ONE 16-byte vector (a half-wave = 512 contiguous bytes of one plane).
+// K loop: stages = (chunk of 16 channels, filter row dy): KS taps x (PSEG pixel rows x COUT/32) MFMAs per wave and
+// stage; xs / ws double-buffered, the next stage requested before the MFMAs and written to LDS after them, one
+// barrier per stage; the stage loop is unrolled over a chunk pair x KS so every LDS access is base + immediate.
+// The chained 1x1 (FUSE): the rounded 8-channel vectors a lane would store are already the B operand (k = 8h + j in
+// NATURAL channel order, thanks to swap23) of the 128 -> 64 conv that consumes them.
+
+#include <stdlib.h>
+#include <type_traits>
+
+#include "c8.h"
+
+namespace codon {
+
+struct ConvC8Params {
+  const uint4* x;
+  const uint4* w;       // packed: [chunk][dy][dx][cb in chunk (2)][cout position] x 16 B
+  uint4* y;
+  const uint4* res;
+  int H, W;
+  long x_img, y_img, r_img;      // 16-byte vectors per image of each buffer: (ctotal / 8) * H * W
+  long x_base, y_base, r_base;   // first vector of the slice inside an image: (coff / 8) * H * W
+  int tiles_x, tiles_y, nblk;
+  int flags;
+  // FUSE only: chained 1x1 (128 -> 64)
+  const uint4* w2;      // [t2][t][g][lane] x 16 B: W1[t2*32 + swap23(lane&31)][t*32 + 16g + 8(lane>>5) + j], j = 0..7
+  uint4* y2;
+  long y2_img, y2_base;
+};
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for_c8(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_c8<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+__device__ __forceinline__ float relu1_c8(float v) {   // one v_max (fmaxf adds a canonicalising v_max(v, v))
+  float o;
+  asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(v));
+  return o;
+}
+
+enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
+
+// pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is
+// 8 MFMAs on 6 operand fetches
+template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : 2; };
+
+template <class E, int KS, int CIN, int COUT, bool FUSE = false>
+__global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
+  typedef typename E::vec8 vec8;
+  typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
+  typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
+  constexpr int PAD = KS / 2;
+  constexpr int PSEG = ConvC8Pseg<KS, COUT>::value;
+  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
+  constexpr int CK = 16, NCB = CK / 8;
+  constexpr int NCHUNK = CIN / CK;
+  constexpr int XS = NCB * XR * XQ;        // 16-byte elements per input tile
+  constexpr int WS = KS * NCB * COUT;      // 16-byte elements per weight stage (one filter row of one chunk)
+  constexpr int CT = COUT / 32;
+  constexpr int NST = NCHUNK * KS;
+  constexpr int XE = (XS + 255) / 256, WE = (WS + 255) / 256;
+  constexpr int XSP = XE * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
+  static_assert(NCHUNK % 2 == 0, "the stage loop is unrolled over chunk pairs");
+  static_assert(2 * XSP * 16 < 65536 && 2 * WSP * 16 < 65536, "LDS immediates are 16 bits per region");
+
+  __shared__ uint4 lds[2 * XSP + 2 * WSP];
+  uint4* const xs0 = lds;
+  uint4* const ws0 = lds + 2 * XSP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int tx0 = tx * TW, ty0 = ty * TH;
+  const int H = p.H, W = p.W;
+  const unsigned HW16 = 16u * (unsigned)H * (unsigned)W;   // bytes per 8-channel plane
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 16), C8_RSRC_FLAGS);
+
+  // gather plan: element e = tid + 256 k = (plane cb of the chunk, row r, col q) of xs[cb][r][q]; xoff = byte offset of
+  // that pixel's vector in plane cb, or out of range (zero padding; padding elements of the last round likewise)
+  unsigned xoff[XE];
+  {
+    constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
+    int cb = tid / (XR * XQ);
+    int rem = tid - cb * (XR * XQ);
+    int r = rem / XQ, q = rem - r * XQ;
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+      const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
+      const bool ok = cb < NCB && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xoff[k] = ok ? (unsigned)cb * HW16 + 16u * (unsigned)(gy * W + gx) : C8_OOB;
+      q += DQ; r += DR; cb += DC;
+      if (q >= XQ) { q -= XQ; r += 1; }
+      if (r >= XR) { r -= XR; cb += 1; }
+    }
+  }
+  const lds_w128 xwr = (lds_w128)(xs0 + tid);
+  const unsigned wvo = (unsigned)tid * 16u;
+  const unsigned wvo_last = (WS % 256 == 0 || tid + (WE - 1) * 256 < WS) ? wvo : C8_OOB;
+  const lds_w128 ww = (lds_w128)(ws0 + tid);
+  const lds_rd xrd = (lds_rd)(xs0 + (half * XR + wave * PSEG) * XQ + l31);
+  const lds_rd wrd = (lds_rd)(ws0 + half * COUT + l31);
+
+  // the next chunk's halo tile is requested in two halves, during the last two filter rows of the current chunk
+  constexpr int XE1 = XE / 2, XEH = XE - XE1;
+  u32x4 xv[XEH];
+  u32x4 wr[WE];
+
+#define LOAD_X(chunk_, k0_, k1_)                                                        \
+  {                                                                                     \
+    const unsigned so_ = (unsigned)(chunk_) * (unsigned)NCB * HW16;                     \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_); \
+  }
+#define STORE_X(buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */            \
+  {                                                                                     \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xwr[(buf_) * XSP + k * 256] = xv[k - (k0_)]; \
+  }
+#define LOAD_W(stage_)                                                                  \
+  {                                                                                     \
+    const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
+      wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * 4096u);              \
+  }
+#define STORE_W(buf_)                                                                   \
+  {                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * 256] = wr[k];  \
+  }
+
+  f32x16 acc[PSEG][CT];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  if constexpr (XE1 > 0) {
+    LOAD_X(0, 0, XE1);
+    STORE_X(0, 0, XE1);
+  }
+  LOAD_X(0, XE1, XE);
+  LOAD_W(0);
+  STORE_X(0, XE1, XE);
+  STORE_W(0);
+  __syncthreads();
+
+  // stage (chunk, dy): weights of filter row dy for 16 channels in ws[(chunk*KS + dy) & 1], the chunk's halo tile in
+  // xs[chunk & 1].  Unrolled over (chunk parity, dy): KS odd, so the stage parity is (par + dy) & 1.
+#pragma unroll 1
+  for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
+    static_for_c8<2 * KS>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int par = u / KS, dy = u % KS;                    // chunk parity, filter row
+      constexpr int sbuf = (par * KS + dy) & 1;                   // c2 is even: stage parity is compile time
+      const int chunk = c2 + par;
+      const int s = chunk * KS + dy;
+      constexpr bool tail = (par == 1 && dy == KS - 1);           // last stage of the pair
+      const bool has_next = !tail || (c2 + 2 < NCHUNK);
+      if (has_next) {
+        LOAD_W(s + 1);
+        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, XE1, XE);
+      }
+      if constexpr (XE1 > 0 && dy == KS - 2) {
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, 0, XE1);
+      }
+
+      // operand fetch one filter tap ahead of its MFMAs, in two register sets.  PIN: sched_barrier holds that order
+      // (measured r2: pinned wins on the 8-MFMA taps of the 5x5 convs, unpinned on the 3x3 ones)
+      constexpr bool PIN = (KS == 5 && PSEG * CT == 8);
+      vec8 a[2][CT], bv[2][PSEG];
+#define FETCH_A(q_, t_)                                                                                   \
+  {                                                                                                       \
+    const u32x4 v_ = wrd[sbuf * WSP + (q_) * NCB * COUT + (t_) * 32];                                     \
+    a[(q_) & 1][t_] = *reinterpret_cast<const vec8*>(&v_);                                                \
+  }
+#define FETCH_B(q_)                                                                                       \
+  {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < PSEG; ++i) {                                                    \
+      const u32x4 v_ = xrd[par * XSP + (dy + i) * XQ + (q_)];                                             \
+      bv[(q_) & 1][i] = *reinterpret_cast<const vec8*>(&v_);                                              \
+    }                                                                                                     \
+  }
+      static_for_c8<CT>([&](auto tc) { FETCH_A(0, decltype(tc)::value) });
+      FETCH_B(0)
+      static_for_c8<KS>([&](auto dc) {
+        constexpr int q = decltype(dc)::value;
+        if constexpr (q + 1 < KS) {
+          FETCH_B(q + 1)
+          static_for_c8<CT>([&](auto tc) { FETCH_A(q + 1, decltype(tc)::value) });
+        }
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i) acc[i][t] = E::mfma(a[q & 1][t], bv[q & 1][i], acc[i][t]);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      });
+#undef FETCH_A
+#undef FETCH_B
+
+      if constexpr (XE1 > 0 && dy == KS - 2) {
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) STORE_X(par ^ 1, 0, XE1);
+      }
+      if (has_next) {
+        STORE_W(sbuf ^ 1);
+        if constexpr (dy == KS - 1) STORE_X(par ^ 1, XE1, XE);
+      }
+      __syncthreads();
+    });
+  }
+#undef LOAD_X
+#undef STORE_X
+#undef LOAD_W
+#undef STORE_W
+
+  // epilogue.  Lane term of every output address: this lane's pixel in plane `half`; the plane pair (t, g) is wave
+  // uniform and goes into the scalar offset.  Off-image pixels are out of range.
+  const int gx = tx0 + l31;
+  unsigned vo[PSEG];
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i) {
+    const int gy = ty0 + wave * PSEG + i;
+    vo[i] = (gx < W && gy < H) ? (unsigned)half * HW16 + 16u * (unsigned)(gy * W + gx) : C8_OOB;
+  }
+  const bool relu = p.flags & CODON_CONV_RELU;
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)((FUSE ? 64 : COUT) / 8) * HW16),
+      C8_RSRC_FLAGS);
+  auto cplane = [&](int t, int g) { return (unsigned)(t * 4 + 2 * g) * HW16; };
+
+  if constexpr (FUSE) {
+    static_assert(!FUSE || COUT == 128, "chained 1x1 is 128 -> 64");
+    u32x4 pk[PSEG][CT][2];
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = acc[i][t][8 * g + j];
+            v8[j] = relu ? relu1_c8(v) : v;
+          }
+          pk[i][t][g] = c8_pack<E>(v8);
+        }
+    if (p.y) {
+      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) c8_st(pk[i][t][g], yrsrc, vo[i], cplane(t, g));
+    }
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 2, C8_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(8u * HW16), C8_RSRC_FLAGS);
+    const unsigned w2vo = (unsigned)lane * 16u;
+    f32x16 d[2][PSEG];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t2][i][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const u32x4 av = c8_ld(w2rsrc, w2vo, (unsigned)(((t2 * CT + t) * 2 + g) * 1024));
+          const vec8 a = *reinterpret_cast<const vec8*>(&av);
+#pragma unroll
+          for (int i = 0; i < PSEG; ++i) d[t2][i] = E::mfma(a, *reinterpret_cast<const vec8*>(&pk[i][t][g]), d[t2][i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) {
+      u32x4 rv[2][2];
+      if (p.res) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) rv[t2][g] = c8_ld(rrsrc, vo[i], cplane(t2, g));
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = d[t2][i][8 * g + j];
+          if (p.res) {
+            float r8[8];
+            c8_unpack<E>(rv[t2][g], r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] += r8[j];
+          }
+          c8_st(c8_pack<E>(v8), y2rsrc, vo[i], cplane(t2, g));
+        }
+    }
+    return;
+  }
+
+  // ReLU / residual / mask / accumulate as compile-time variants selected by wave-uniform branches
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    constexpr int RES = decltype(res_c)::value;
+    constexpr bool ACC = decltype(acc_c)::value;
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        u32x4 rv[2], av[2];
+        if constexpr (RES != RESC8_NONE) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) rv[g] = c8_ld(rrsrc, vo[i], cplane(t, g));
+        }
+        if constexpr (ACC) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) av[g] = c8_ld(yrsrc, vo[i], cplane(t, g));
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float v8[8], r8[8], a8[8];
+          if constexpr (RES != RESC8_NONE) c8_unpack<E>(rv[g], r8);
+          if constexpr (ACC) c8_unpack<E>(av[g], a8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = acc[i][t][8 * g + j];
+            if constexpr (RELU) v = relu1_c8(v);
+            if constexpr (RES == RESC8_ADD) v += r8[j];
+            if constexpr (RES == RESC8_MASK) v = r8[j] > 0.f ? v : 0.f;
+            if constexpr (ACC) v += a8[j];
+            v8[j] = v;
+          }
+          c8_st(c8_pack<E>(v8), yrsrc, vo[i], cplane(t, g));
+        }
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using R0 = std::integral_constant<int, RESC8_NONE>;
+  using R1 = std::integral_constant<int, RESC8_ADD>;
+  using R2 = std::integral_constant<int, RESC8_MASK>;
+  const int res_mode = !p.res ? RESC8_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RESC8_MASK
+                                           : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RESC8_ADD : RESC8_NONE;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  auto by_acc = [&](auto relu_c, auto res_c) {
+    if (accum) epi(relu_c, res_c, T{});
+    else epi(relu_c, res_c, F{});
+  };
+  auto by_res = [&](auto relu_c) {
+    if (res_mode == RESC8_NONE) by_acc(relu_c, R0{});
+    else if (res_mode == RESC8_ADD) by_acc(relu_c, R1{});
+    else by_acc(relu_c, R2{});
+  };
+  if (relu) by_res(T{});
+  else by_res(F{});
+}
+
+// ---- 1x1 convolution (stand-alone confuse* and their dgrad): HBM-bound ---------------------------------------------
+// Y[co][pix] = sum_ci W[co][ci] X[ci][pix]: a plain GEMM over the flattened pixels of one image, no halo, no LDS.  A
+// wave owns 64 consecutive pixels (two 32-pixel MFMA column tiles) and all COUT rows.  B fragment of lane (pixel,
+// half h) for k-step ks = the 16-byte vector of plane 2 ks + h at that pixel: one buffer_load_b128 (a half-wave reads
+// 512 contiguous bytes).  All of a wave's activation loads are issued before its first MFMA.  A fragment = 16 bytes
+// of the packed weight image (<= 16 KB, L1/L2 resident), straight from global.  Epilogue as the k x k kernel.
+template <class E, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_c8_kernel(const ConvC8Params p) {
+  typedef typename E::vec8 vec8;
+  constexpr int NKS = CIN / 16, CT = COUT / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const long HW = (long)p.H * p.W;
+  const unsigned HW16 = 16u * (unsigned)HW;
+  const int b = blockIdx.y;
+  const long pix0 = ((long)blockIdx.x * 4 + wave) * 64;     // first pixel of this wave's group
+  if (pix0 >= HW) return;                                    // wave-uniform
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(CIN * COUT * 2), C8_RSRC_FLAGS);
+  const bool relu = p.flags & CODON_CONV_RELU;
+  const bool rg = p.res != nullptr;
+  const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
+  const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+
+  unsigned vo[2];                                            // tile i: pixel pix0 + 32 i + l31, plane `half`
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long px = pix0 + i * 32 + l31;
+    vo[i] = px < HW ? (unsigned)half * HW16 + 16u * (unsigned)px : C8_OOB;
+  }
+  u32x4 dd[NKS][2];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dd[ks][i] = c8_ld(xrsrc, vo[i], (unsigned)(2 * ks) * HW16);
+
+  // the COUT rows are processed 64 at a time; the residual / mask / accumulate vectors of a half are requested before
+  // its MFMAs, so a wave makes one memory round trip per half
+  constexpr int CTB = CT > 2 ? 2 : CT;
+  auto cplane = [&](int t, int g) { return (unsigned)(t * 4 + 2 * g) * HW16; };
+  auto half_pass = [&](auto has_r, auto has_acc, const int t0) {
+    constexpr bool HR = decltype(has_r)::value, HA = decltype(has_acc)::value;
+    u32x4 rm[2][CTB][2], am[2][CTB][2];
+    if constexpr (HR) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < CTB; ++t)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) rm[i][t][g] = c8_ld(rrsrc, vo[i], cplane(t0 + t, g));
+    }
+    if constexpr (HA) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < CTB; ++t)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) am[i][t][g] = c8_ld(yrsrc, vo[i], cplane(t0 + t, g));
+    }
+    f32x16 acc[2][CTB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < CTB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      vec8 a[CTB];
+#pragma unroll
+      for (int t = 0; t < CTB; ++t) {
+        const u32x4 v = c8_ld(wrsrc, (unsigned)((half * COUT + (t0 + t) * 32 + l31) * 16), (unsigned)(ks * 2 * COUT * 16));
+        a[t] = *reinterpret_cast<const vec8*>(&v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < CTB; ++t)
+          acc[i][t] = E::mfma(a[t], *reinterpret_cast<const vec8*>(&dd[ks][i]), acc[i][t]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < CTB; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float v8[8], r8[8], a8[8];
+          if constexpr (HR) c8_unpack<E>(rm[i][t][g], r8);
+          if constexpr (HA) c8_unpack<E>(am[i][t][g], a8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = acc[i][t][8 * g + j];
+            if (relu) v = fmaxf(v, 0.f);
+            if constexpr (HR) {
+              if (addr) v += r8[j];
+              if (mask) v = r8[j] > 0.f ? v : 0.f;
+            }
+            if constexpr (HA) v += a8[j];
+            v8[j] = v;
+          }
+          c8_st(c8_pack<E>(v8), yrsrc, vo[i], cplane(t0 + t, g));
+        }
+  };
+  const bool has_r = addr || mask;
+#pragma unroll
+  for (int t0 = 0; t0 < CT; t0 += CTB) {
+    if (has_r && accum) half_pass(std::true_type{}, std::true_type{}, t0);
+    else if (has_r) half_pass(std::true_type{}, std::false_type{}, t0);
+    else if (accum) half_pass(std::false_type{}, std::true_type{}, t0);
+    else half_pass(std::false_type{}, std::false_type{}, t0);
+  }
+}
+
+// ---- weight packers -------------------------------------------------------------------------------------------------
+// OIHW fp32 -> 16-bit packed [chunk][dy][dx][cb (2)][cout position][8 ch]; position p of a 32-row tile holds cout
+// tile*32 + swap23(p & 31).  DGRAD: flipped taps, in/out swapped (the same kernel then computes dL/dx).
+template <class E>
+__global__ void pack_weight_c8_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout, int cin,
+                                      int ks, int dgrad) {
+  const int kin = dgrad ? cout : cin, kout = dgrad ? cin : cout;
+  const long n = (long)kin * kout * ks * ks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int j = t % 8; t /= 8;
+    const int op = t % kout; t /= kout;
+    const int cb = t % 2; t /= 2;
+    const int dx = t % ks; t /= ks;
+    const int dy = t % ks; t /= ks;
+    const int chunk = (int)t;
+    const int o = (op & ~31) | swap23(op & 31);
+    const int ci = chunk * 16 + cb * 8 + j;
+    float v;
+    if (!dgrad) v = w[(((long)o * cin + ci) * ks + dy) * ks + dx];
+    else v = w[(((long)ci * cin + o) * ks + (ks - 1 - dy)) * ks + (ks - 1 - dx)];
+    out[i] = (unsigned short)(E::pack2(v, 0.f) & 0xffffu);
+  }
+}
+
+// OIHW (64,128,1,1) fp32 -> the chained-1x1 A-operand image [t2][t][g][lane][8]
+template <class E>
+__global__ void pack_chain1x1_c8_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 64 * 128 values
+  if (i >= 64 * 128) return;
+  const int j = i & 7, lane = (i >> 3) & 63, g = (i >> 9) & 1, t = (i >> 10) & 3, t2 = i >> 12;
+  const int co2 = t2 * 32 + swap23(lane & 31);
+  const int c = t * 32 + 16 * g + 8 * (lane >> 5) + j;
+  out[i] = (unsigned short)(E::pack2(w[co2 * 128 + c], 0.f) & 0xffffu);
+}
+
+int pack_chain1x1_16(const float* w, void* out, int dtype, hipStream_t stream) {
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(pack_chain1x1_c8_kernel<C8F16>, dim3(32), dim3(256), 0, stream, w, (unsigned short*)out);
+  else
+    hipLaunchKernelGGL(pack_chain1x1_c8_kernel<C8Bf16>, dim3(32), dim3(256), 0, stream, w, (unsigned short*)out);
+  return check_launch("pack_chain1x1_c8_kernel");
+}
+
+int pack_weight_bf16(const float* w, void* out, int cout, int cin, int ks, int mode, int dtype, hipStream_t stream) {
+  const long n = (long)cout * cin * ks * ks;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  const int kout = mode == CODON_PACK_DGRAD ? cin : cout;
+  CODON_REQUIRE(kout % 32 == 0, CODON_ERR_UNSUPPORTED, "conv_pack_weight: 16-bit packing needs 32-row output tiles (got %d)", kout);
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(pack_weight_c8_kernel<C8F16>, dim3(blocks), dim3(256), 0, stream, w, (unsigned short*)out, cout,
+                       cin, ks, mode == CODON_PACK_DGRAD ? 1 : 0);
+  else
+    hipLaunchKernelGGL(pack_weight_c8_kernel<C8Bf16>, dim3(blocks), dim3(256), 0, stream, w, (unsigned short*)out, cout,
+                       cin, ks, mode == CODON_PACK_DGRAD ? 1 : 0);
+  return check_launch("pack_weight_c8_kernel");
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static bool c8_desc_ok(const codon_conv_desc* d, bool with_res) {
+  if (!c8_slice_ok(d->x_ctotal, d->x_coff, d->cin) || !c8_slice_ok(d->y_ctotal, d->y_coff, d->cout)) return false;
+  if (with_res && !c8_slice_ok(d->r_ctotal, d->r_coff, d->cout)) return false;
+  return true;
+}
+
+static void c8_fill(ConvC8Params& p, const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res) {
+  const long HW = (long)d->height * d->width;
+  p.x = (const uint4*)x; p.w = (const uint4*)w; p.y = (uint4*)y; p.res = (const uint4*)res;
+  p.H = d->height; p.W = d->width;
+  p.x_img = (d->x_ctotal / 8) * HW; p.y_img = (d->y_ctotal / 8) * HW; p.r_img = (d->r_ctotal / 8) * HW;
+  p.x_base = (d->x_coff / 8) * HW; p.y_base = (d->y_coff / 8) * HW; p.r_base = (d->r_coff / 8) * HW;
+  p.tiles_x = p.tiles_y = p.nblk = 0;
+  p.flags = d->flags;
+  p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
+}
+
+template <class E, int CIN, int COUT>
+static int launch_conv1x1_c8(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                             hipStream_t stream) {
+  ConvC8Params p;
+  c8_fill(p, d, x, w, y, res);
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(d->batch <= 65535, CODON_ERR_UNSUPPORTED, "conv2d_fwd: batch %d > 65535", d->batch);
+  const unsigned gx = (unsigned)((HW + 255) / 256);
+  hipLaunchKernelGGL((conv1x1_c8_kernel<E, CIN, COUT>), dim3(gx, d->batch), dim3(256), 0, stream, p);
+  return check_launch("conv1x1_c8_kernel");
+}
+
+template <class E, int KS, int CIN, int COUT, bool FUSE>
+static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
+  constexpr int TH = 4 * ConvC8Pseg<KS, COUT>::value;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + TH - 1) / TH;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  return check_launch("conv_c8_kernel");
+}
+
+template <class E>
+static int conv2d_fwd_c8(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                         hipStream_t stream) {
+  ConvC8Params p;
+  c8_fill(p, d, x, w, y, res);
+  const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
+  switch (key) {
+    case 5128128: return launch_conv_c8<E, 5, 128, 128, false>(p, d, stream);
+    case 5064064: return launch_conv_c8<E, 5, 64, 64, false>(p, d, stream);
+    case 3064064: return launch_conv_c8<E, 3, 64, 64, false>(p, d, stream);
+    case 3128064: return launch_conv_c8<E, 3, 128, 64, false>(p, d, stream);
+    case 3064128: return launch_conv_c8<E, 3, 64, 128, false>(p, d, stream);
+    case 1128064: return launch_conv1x1_c8<E, 128, 64>(d, x, w, y, res, stream);
+    case 1064128: return launch_conv1x1_c8<E, 64, 128>(d, x, w, y, res, stream);
+    default:
+      set_error("conv2d_fwd: no 16-bit kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      return CODON_ERR_UNSUPPORTED;
+  }
+}
+
+int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* res,
+                    hipStream_t stream) {
+  const bool with_res = res && (d->flags & (CODON_CONV_ADD_RESIDUAL | CODON_CONV_MASK_RELU));
+  CODON_REQUIRE(c8_desc_ok(d, with_res), CODON_ERR_BAD_ARG,
+                "conv2d_fwd: 16-bit tensors are channel-blocked: ctotal / coff / channels must be multiples of 8");
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_fwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  return d->dtype == CODON_F16 ? conv2d_fwd_c8<C8F16>(d, x, w, y, with_res ? res : nullptr, stream)
+                               : conv2d_fwd_c8<C8Bf16>(d, x, w, y, with_res ? res : nullptr, stream);
+}
+
+int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,
+                         const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+  CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: 16-bit kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
+  CODON_REQUIRE(c8_slice_ok(d->x_ctotal, d->x_coff, 128) && (!y || c8_slice_ok(d->y_ctotal, d->y_coff, 128)) &&
+                    c8_slice_ok(out->ctotal, out->coff, 64) && (!res || c8_slice_ok(res->ctotal, res->coff, 64)),
+                CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_fwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  ConvC8Params p;
+  c8_fill(p, d, x, w, y, res ? res->data : nullptr);
+  if (!y) { p.y_img = p.y_base = 0; }
+  p.r_img = res ? (res->ctotal / 8) * HW : 0;
+  p.r_base = res ? (res->coff / 8) * HW : 0;
+  p.w2 = (const uint4*)w_chain; p.y2 = (uint4*)out->data;
+  p.y2_img = (out->ctotal / 8) * HW; p.y2_base = (out->coff / 8) * HW;
+  return d->dtype == CODON_F16 ? launch_conv_c8<C8F16, 5, 128, 128, true>(p, d, stream)
+                               : launch_conv_c8<C8Bf16, 5, 128, 128, true>(p, d, stream);
+}
+
+}  // namespace codon

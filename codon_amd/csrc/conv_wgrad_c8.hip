@@ -1,0 +1,340 @@
+// 16-bit weight gradient over CHANNEL-BLOCKED tensors (c8.h): v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate, fp32 dW.
+//
+//   dW[co][ci][dy][dx] = sum_{b,h,w} gy[b,co,h,w] * x[b,ci,h+dy-p,w+dx-p]        (autograd of nn.Conv2d;
+//                                                  the reference has no explicit backward)
+//
+// GEMM: M = cout, N = cin (per tap), K = pixels; one MFMA consumes 16 pixels of one image row, 8 per lane:
+//   A (32 x 16): lane l holds gy[co = l&31][pix 8h .. 8h+7]
+//   B (16 x 32): lane l holds x [ci = l&31][pix 8h + dx - p .. + 7]
+// Both operands want PIXELS along the lane's 8 elements, the C8 layout has CHANNELS there -- the LDS tiles therefore
+// keep the HBM form (plane-major [8-channel plane][pixel][8 ch], staging = straight 16-byte copies, conflict-free
+// ds_write_b128) and the transpose is done by the gfx950 transposing read ds_read_b64_tr_b16: a 16-lane group reads
+// 4 pixels x 16 channels (two planes) and every lane receives ONE channel's 4 pixels.  Plane pitch = 64 (mod 256)
+// bytes, so the four planes a half-wave touches sit on four disjoint bank quarters: conflict-free.
+// A wave owns one filter ROW dy and one 32-cout tile.  The KS shifted B fragments of a k-step overlap in all but KS-1
+// pixels, so the lane reads ONE 12-pixel window of its channel (three transposing reads) and derives the KS fragments
+// in registers: even shift = a register offset, odd shift = four v_alignbit_b32.  Per k-step: 2 + 3 reads of 512 B
+// for KS MFMAs.  In pixel-major LDS every shift is a whole-vector offset, so there is no W % 8 condition.
+//
+// Workgroup = 2*KS waves = (2 cout tiles) x (KS filter rows): 64 cout x 32 cin x all taps, streaming an image band in
+// 4 x 32 pixel tiles, LDS double-buffered.  Partials -> workspace[split][tap][co][ci] (fp32), summed in fixed order by
+// wgrad_reduce_kernel: deterministic.  k = 1 (confuse*): 8 waves = 2 cout tiles x 4 tile rows over 128 cin, partials
+// summed through LDS.
+
+#include "c8.h"
+
+namespace codon {
+
+constexpr int WC8_TH = 4;
+constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
+
+struct WgradC8Params {
+  const uint4* x;
+  const uint4* gy;
+  float* ws;
+  int H, W, cin, cout;
+  long x_img, g_img, x_base, g_base;   // 16-byte vectors
+  int tiles_x, nbands, nsplit;
+};
+
+template <class E, int KS>
+__global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
+  typedef typename E::vec8 vec8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  constexpr bool KSPLIT = (KS == 1);
+  constexpr int CIB = KSPLIT ? WC8_CIB1 : 1;     // 32-cin tiles per workgroup
+  constexpr int NT = KSPLIT ? 2 * WC8_TH * 64 : 2 * KS * 64;
+  constexpr int PAD = KS / 2;
+  constexpr int TW = 32, TH = WC8_TH;
+  constexpr int XC = KSPLIT ? TW : TW + 4;       // tile columns: origin tx0 - PAD; the 12-pixel windows reach column 35
+  constexpr int XR = TH + KS - 1;
+  constexpr int XPL = 4 * CIB, GPL = 8;          // 8-channel planes per tile
+  constexpr int pitch64 = 64;
+  constexpr int XPITCH = ((XR * XC * 16 - pitch64 + 255) / 256) * 256 + pitch64;   // == 64 (mod 256), >= plane bytes
+  constexpr int GPITCH = ((TH * TW * 16 - pitch64 + 255) / 256) * 256 + pitch64;
+  static_assert(XPITCH >= XR * XC * 16 && GPITCH >= TH * TW * 16, "plane pitch covers the plane");
+  constexpr int XBYTES = XPL * XPITCH, GBYTES = GPL * GPITCH;
+  constexpr int NXE = XPL * XR * XC, NGE = GPL * TH * TW;   // 16-byte elements per tile
+  constexpr int XE = (NXE + NT - 1) / NT, GE = (NGE + NT - 1) / NT;
+  constexpr int NK = TH * (TW / 16);
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (XBYTES + GBYTES)];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int H = p.H, W = p.W;
+  const long HW = (long)H * W;
+  const unsigned HW16 = 16u * (unsigned)HW;
+
+  const int nci_t = p.cin / (32 * CIB);
+  // the channel blocks that read the SAME image band go to one XCD (they share the band in that L2)
+  const unsigned vb_ = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bx_ = (int)(vb_ % gridDim.x), by_ = (int)(vb_ / gridDim.x);
+  const int cob = bx_ / nci_t, cib = bx_ % nci_t;   // 64-cout block, 32*CIB-cin block
+  const int split = by_;
+  const int b = split / p.nbands, band = split % p.nbands;
+  const int tiles_y = (H + TH - 1) / TH;
+  const int ty_begin = (int)((long)band * tiles_y / p.nbands);          // tile rows spread evenly over the bands
+  const int ty_end = (int)((long)(band + 1) * tiles_y / p.nbands);
+  const int ntile = (ty_end - ty_begin) * p.tiles_x;
+
+  const uint4* const xg = p.x + b * p.x_img + p.x_base + (long)cib * XPL * HW;
+  const uint4* const gg = p.gy + b * p.g_img + p.g_base + (long)cob * GPL * HW;
+
+  // staging plan (tile independent): element e = tid + NT k = (plane, row, col)
+  unsigned xrel[XE], grel[GE];      // byte offset relative to the tile origin
+  int xrc[XE], grc[GE];             // (row << 8) | col, or -1 for the padding elements of the last round
+  int xlds[XE], glds[GE];           // LDS byte address inside a buffer
+#pragma unroll
+  for (int k = 0; k < XE; ++k) {
+    const int e = tid + k * NT;
+    const int q = e % XC, r = (e / XC) % XR, c = e / (XC * XR);
+    const bool in = (NXE % NT == 0) || e < NXE;
+    xrel[k] = (unsigned)c * HW16 + 16u * (unsigned)(r * W + q);
+    xrc[k] = in ? ((r << 8) | q) : -1;
+    xlds[k] = in ? c * XPITCH + (r * XC + q) * 16 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < GE; ++k) {
+    const int e = tid + k * NT;
+    const int q = e % TW, r = (e / TW) % TH, c = e / (TW * TH);
+    const bool in = (NGE % NT == 0) || e < NGE;
+    grel[k] = (unsigned)c * HW16 + 16u * (unsigned)(r * W + q);
+    grc[k] = in ? ((r << 8) | q) : -1;
+    glds[k] = in ? c * GPITCH + (r * TW + q) * 16 : 0;
+  }
+
+  const int co_t = wave & 1, dy = KSPLIT ? 0 : (wave >> 1);
+  const int krow = wave >> 1;   // KSPLIT: the tile row whose k-steps this wave takes
+  // transposing-read lane addresses: lane 4q+p of a 16-lane group supplies pixel q, channels 4p..4p+3 of the group's 16
+  const int li = lane & 15, tq = li >> 2, tp = li & 3, cblk = (lane >> 4) & 1;
+  const int a_lane = (co_t * 4 + 2 * cblk + (tp >> 1)) * GPITCH + (8 * half + tq) * 16 + (tp & 1) * 8;
+  const int b_lane = (2 * cblk + (tp >> 1)) * XPITCH + (dy * XC + 8 * half + tq) * 16 + (tp & 1) * 8;
+
+  constexpr int NACC = KSPLIT ? CIB : KS;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  u32x4 xv[XE], gv[GE];
+  auto load_tile = [&](int t) {
+    const int ty = ty_begin + t / p.tiles_x, tx = t % p.tiles_x;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    // the tile origin (possibly before the slice start: such elements are masked) goes into the descriptor base
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xg + ((long)(ty0 - PAD) * W + (tx0 - PAD))), 0, (int)C8_OOB, C8_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gg + ((long)ty0 * W + tx0)), 0, (int)C8_OOB, C8_RSRC_FLAGS);
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+      const int gy_ = ty0 - PAD + (xrc[k] >> 8), gx_ = tx0 - PAD + (xrc[k] & 255);
+      const bool ok = xrc[k] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+      xv[k] = c8_ld(xr, ok ? xrel[k] : C8_OOB, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      const int gy_ = ty0 + (grc[k] >> 8), gx_ = tx0 + (grc[k] & 255);
+      const bool ok = grc[k] >= 0 && gy_ < H && gx_ < W;
+      gv[k] = c8_ld(gr, ok ? grel[k] : C8_OOB, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* xs = lds + buf * (XBYTES + GBYTES);
+    unsigned char* gs = xs + XBYTES;
+#pragma unroll
+    for (int k = 0; k < XE; ++k)
+      if ((NXE % NT == 0) || tid + k * NT < NXE) *reinterpret_cast<u32x4*>(xs + xlds[k]) = xv[k];
+#pragma unroll
+    for (int k = 0; k < GE; ++k)
+      if ((NGE % NT == 0) || tid + k * NT < NGE) *reinterpret_cast<u32x4*>(gs + glds[k]) = gv[k];
+  };
+
+  if (ntile > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+#define TR_READ(ptr_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr_))
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const bool has_next = t + 1 < ntile;
+    if (has_next) load_tile(t + 1);
+
+    const unsigned char* xs = lds + (t & 1) * (XBYTES + GBYTES);
+    const unsigned char* gs = xs + XBYTES;
+    s16x4 a2[2][2], wd[2][3], wk[CIB][2];
+#define WC8_READ(ks_, s_)                                                                    \
+    {                                                                                        \
+      const int r_ = (ks_) / (TW / 16), c0_ = ((ks_) % (TW / 16)) * 16;                      \
+      const unsigned char* ap_ = gs + a_lane + (r_ * TW + c0_) * 16;                         \
+      a2[s_][0] = TR_READ(ap_);                                                              \
+      a2[s_][1] = TR_READ(ap_ + 64);                                                         \
+      const unsigned char* bp_ = xs + b_lane + (r_ * XC + c0_) * 16;                         \
+      if constexpr (KSPLIT) {                                                                \
+        _Pragma("unroll") for (int j = 0; j < CIB; ++j) {                                    \
+          wk[j][0] = TR_READ(bp_ + j * 4 * XPITCH);                                          \
+          wk[j][1] = TR_READ(bp_ + j * 4 * XPITCH + 64);                                     \
+        }                                                                                    \
+      } else {                                                                               \
+        wd[s_][0] = TR_READ(bp_);                                                            \
+        wd[s_][1] = TR_READ(bp_ + 64);                                                       \
+        wd[s_][2] = TR_READ(bp_ + 128);                                                      \
+      }                                                                                      \
+    }
+    if constexpr (KSPLIT) {
+#pragma unroll
+      for (int c = 0; c < TW / 16; ++c) {
+        WC8_READ(krow * (TW / 16) + c, 0)
+        union { struct { s16x4 l, h; } s; vec8 v; } ua;
+        ua.s.l = a2[0][0]; ua.s.h = a2[0][1];
+#pragma unroll
+        for (int j = 0; j < CIB; ++j) {
+          union { struct { s16x4 l, h; } s; vec8 v; } ub;
+          ub.s.l = wk[j][0]; ub.s.h = wk[j][1];
+          acc[j] = E::mfma(ua.v, ub.v, acc[j]);
+        }
+      }
+    } else {
+      WC8_READ(0, 0)
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < NK) WC8_READ(ks + 1, cur ^ 1)
+        union { struct { s16x4 l, h; } s; vec8 v; } ua;
+        ua.s.l = a2[cur][0]; ua.s.h = a2[cur][1];
+        // window words w[0..5] = pixels 0 .. 11 past (row, c0 + 8h) of the lane's channel; tap dx = elements dx .. dx+7
+        union { s16x4 v[3]; unsigned w[6]; } uw;
+        uw.v[0] = wd[cur][0]; uw.v[1] = wd[cur][1]; uw.v[2] = wd[cur][2];
+        const unsigned* w = uw.w;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const int m = dx / 2;
+          u32x4 f;
+          if (dx % 2 == 0) {
+            f = u32x4{w[m], w[m + 1], w[m + 2], w[m + 3]};
+          } else {
+            f = u32x4{__builtin_amdgcn_alignbit(w[m + 1], w[m], 16), __builtin_amdgcn_alignbit(w[m + 2], w[m + 1], 16),
+                      __builtin_amdgcn_alignbit(w[m + 3], w[m + 2], 16), __builtin_amdgcn_alignbit(w[m + 4], w[m + 3], 16)};
+          }
+          acc[dx] = E::mfma(ua.v, *reinterpret_cast<const vec8*>(&f), acc[dx]);
+        }
+      }
+    }
+#undef WC8_READ
+    if (has_next) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+#undef TR_READ
+
+  float* __restrict__ wsp = p.ws + (long)split * (KS * KS) * p.cout * p.cin;
+  if constexpr (KSPLIT) {
+    // sum the TH row-group partials of each (cout tile, cin tile) in fixed order (deterministic) through LDS
+    float* red = reinterpret_cast<float*>(lds);                  // [krow][co_t][16][64] floats = 8 KB per row group
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((krow * 2 + co_t) * 16 + r) * 64 + lane] = acc[j][r];
+      __syncthreads();
+      if (krow == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = red[((0 * 2 + co_t) * 16 + r) * 64 + lane];
+#pragma unroll
+          for (int g = 1; g < TH; ++g) v += red[((g * 2 + co_t) * 16 + r) * 64 + lane];
+          const int co = cob * 64 + co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          wsp[(long)co * p.cin + (cib * CIB + j) * 32 + l31] = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx) {
+    const int tap = dy * KS + dx;
+    const int ci = cib * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cob * 64 + co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      wsp[((long)tap * p.cout + co) * p.cin + ci] = acc[dx][r];
+    }
+  }
+}
+
+// defined in conv_wgrad_f32.hip: dw[co][ci][tap] (+)= sum_s ws[s][tap][co][ci], fixed order
+int launch_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
+                        hipStream_t stream);
+
+#ifndef CODON_WGRAD16_TARGET
+#define CODON_WGRAD16_TARGET 256
+#endif
+constexpr int WGRAD16_TARGET_BLOCKS = CODON_WGRAD16_TARGET;   // workgroups per launch the band split aims for
+
+struct Wgrad16Plan {
+  int nbands, nsplit, nchan_blocks;
+};
+
+static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
+  const int k = d->ksize, ci = d->cin, co = d->cout;
+  if (!((k == 1 || k == 3 || k == 5) && ci % 32 == 0 && co % 64 == 0)) return false;
+  if (k == 1 && ci % (32 * WC8_CIB1) != 0) return false;
+  pl->nchan_blocks = (co / 64) * (ci / (k == 1 ? 32 * WC8_CIB1 : 32));
+  const int tiles_y = (d->height + WC8_TH - 1) / WC8_TH;
+  int want = (WGRAD16_TARGET_BLOCKS + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);
+  if (want < 1) want = 1;
+  if (want > tiles_y) want = tiles_y;
+  pl->nbands = want;
+  pl->nsplit = d->batch * pl->nbands;
+  return true;
+}
+
+size_t conv_wgrad_bf16_workspace_bytes(const codon_conv_desc* d) {
+  Wgrad16Plan pl;
+  if (!wgrad16_plan(d, &pl)) return 0;
+  return (size_t)pl.nsplit * d->cout * d->cin * d->ksize * d->ksize * sizeof(float);
+}
+
+int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, float* dw, float* workspace,
+                      size_t ws_bytes, int accumulate, hipStream_t stream) {
+  Wgrad16Plan pl;
+  if (!wgrad16_plan(d, &pl)) {
+    set_error("conv2d_wgrad: no 16-bit kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+    return CODON_ERR_UNSUPPORTED;
+  }
+  CODON_REQUIRE(c8_slice_ok(d->x_ctotal, d->x_coff, d->cin) && c8_slice_ok(d->y_ctotal, d->y_coff, d->cout),
+                CODON_ERR_BAD_ARG, "conv2d_wgrad: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
+  CODON_REQUIRE(ws_bytes >= conv_wgrad_bf16_workspace_bytes(d), CODON_ERR_BAD_ARG,
+                "conv2d_wgrad: workspace %zu B < required %zu B", ws_bytes, conv_wgrad_bf16_workspace_bytes(d));
+  CODON_REQUIRE(pl.nsplit <= 65535, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: %d splits > 65535", pl.nsplit);
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_wgrad: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  WgradC8Params p;
+  p.x = (const uint4*)x; p.gy = (const uint4*)gy; p.ws = workspace;
+  p.H = d->height; p.W = d->width; p.cin = d->cin; p.cout = d->cout;
+  p.x_img = (d->x_ctotal / 8) * HW; p.g_img = (d->y_ctotal / 8) * HW;
+  p.x_base = (d->x_coff / 8) * HW; p.g_base = (d->y_coff / 8) * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.nbands = pl.nbands; p.nsplit = pl.nsplit;
+  const dim3 grid(pl.nchan_blocks, pl.nsplit);
+  const bool f16 = d->dtype == CODON_F16;
+  if (d->ksize == 5) {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, dim3(640), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, dim3(640), 0, stream, p);
+  } else if (d->ksize == 3) {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(384), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(384), 0, stream, p);
+  } else {
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  }
+  const int st = check_launch("conv_wgrad_c8_kernel");
+  if (st != CODON_OK) return st;
+  return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
+}
+
+}  // namespace codon

@@ -1,14 +1,14 @@
 // Stem (1->64, 3x3, ReLU) and head (64->1, 3x3, + global residual) stencils: HBM-bound VALU kernels.
 //   stem: self.relu(self.input(x)) / self.relu(self.input_c(y))   CODON_x4.py:68,71
 //   head: torch.add(self.output(out), residual)                    CODON_x4.py:130-131
-// Both walk NCHW rows with VEC consecutive pixels per lane, so a wave touches 64*VEC*4
+// fp32 activations (NCHW): both walk rows with VEC consecutive pixels per lane, so a wave touches 64*VEC*4
 // contiguous bytes per load/store instruction (1 KiB at VEC=4).  VEC=4 needs W % 4 == 0 (every
 // plane row is then 16-byte aligned); other widths take the VEC=1 instantiation.
+// 16-bit activations are channel-blocked (c8.h) and take the kernels of ew_c8.hip.
 
 #include <type_traits>
 
 #include "codon_common.h"
-#include "px8.h"
 
 namespace codon {
 
@@ -19,40 +19,15 @@ struct Vec<4> { using T = float4; };
 template <>
 struct Vec<1> { using T = float; };
 
-// element accessors: T = float (fp32 activations) or u16_t (bf16 activations); math is always fp32
+// element accessors (fp32 activations; math is always fp32)
 __device__ __forceinline__ float ldx(const float* p) { return *p; }
-__device__ __forceinline__ float ldx(const u16_t* p) { return b2f(*p); }
-__device__ __forceinline__ float ldx(const h16_t* p) { return h2f(p->bits); }
-__device__ __forceinline__ void stx(h16_t* p, float v) { p->bits = f2h(v); }
-__device__ __forceinline__ void ld4(const h16_t* p, float (&o)[4]) {
-  const uint2 c = *reinterpret_cast<const uint2*>(p);
-  o[0] = CvtH16::lo(c.x); o[1] = CvtH16::hi(c.x); o[2] = CvtH16::lo(c.y); o[3] = CvtH16::hi(c.y);
-}
-__device__ __forceinline__ void st4(h16_t* p, const float (&o)[4]) {
-  uint2 c;
-  c.x = (unsigned)f2h(o[0]) | ((unsigned)f2h(o[1]) << 16);
-  c.y = (unsigned)f2h(o[2]) | ((unsigned)f2h(o[3]) << 16);
-  *reinterpret_cast<uint2*>(p) = c;
-}
 __device__ __forceinline__ void stx(float* p, float v) { *p = v; }
-__device__ __forceinline__ void stx(u16_t* p, float v) { *p = f2b(v); }
 __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
   const float4 c = *reinterpret_cast<const float4*>(p);
   o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
 }
-__device__ __forceinline__ void ld4(const u16_t* p, float (&o)[4]) {
-  const uint2 c = *reinterpret_cast<const uint2*>(p);
-  o[0] = __uint_as_float(c.x << 16); o[1] = __uint_as_float(c.x & 0xffff0000u);
-  o[2] = __uint_as_float(c.y << 16); o[3] = __uint_as_float(c.y & 0xffff0000u);
-}
 __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
-}
-__device__ __forceinline__ void st4(u16_t* p, const float (&o)[4]) {
-  uint2 c;
-  c.x = (unsigned)f2b(o[0]) | ((unsigned)f2b(o[1]) << 16);
-  c.y = (unsigned)f2b(o[2]) | ((unsigned)f2b(o[3]) << 16);
-  *reinterpret_cast<uint2*>(p) = c;
 }
 
 template <int VEC, typename T>
@@ -140,7 +115,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 // channel it loads the band's R + 2 rows ONCE and produces all R output rows from registers, so an input element is
 // fetched (R + 2) / R times instead of 3 (round 1: one row per thread, 6.08 GB moved for 2.60 GB algorithmic -- the
 // vertically adjacent rows sat in other workgroups on other XCDs, whose L2s each fetched them again).
-// 16-bit activations take VEC = 8 (16-byte accesses), fp32 VEC = 4; VEC = 1 for widths that are not a multiple.
+// VEC = 4 (16-byte accesses); VEC = 1 for widths that are not a multiple.  16-bit activations: head_c8_kernel (ew_c8.hip).
 template <int VEC, int R, typename T>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ res, float* __restrict__ y, int H,
@@ -194,40 +169,20 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, cons
       const bool rowok = gy >= 0 && gy < H;                       // wave-uniform
       const __amdgpu_buffer_rsrc_t rs = rowok ? rs_img : rs_nil;
       const unsigned so = ((unsigned)c * (unsigned)HW + (unsigned)(rowok ? gy : 0) * (unsigned)W) * ES;
-      if constexpr (ES == 4) {
-        if constexpr (VEC == 4) {
-          const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
-          const float4 f = *reinterpret_cast<const float4*>(&v);
-          rw[j][1] = f.x; rw[j][2] = f.y; rw[j][3] = f.z; rw[j][4] = f.w;
-        } else if constexpr (VEC == 2) {
-          const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
-          const float2 f = *reinterpret_cast<const float2*>(&v);
-          rw[j][1] = f.x; rw[j][2] = f.y;
-        } else {
-          rw[j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
-        }
-        rw[j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vl, so, 0));
-        rw[j][VEC + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vr, so, 0));
+      static_assert(ES == 4, "head_kernel is the fp32 (NCHW) kernel; 16-bit tensors take head_c8_kernel");
+      if constexpr (VEC == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+        const float4 f = *reinterpret_cast<const float4*>(&v);
+        rw[j][1] = f.x; rw[j][2] = f.y; rw[j][3] = f.z; rw[j][4] = f.w;
+      } else if constexpr (VEC == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+        const float2 f = *reinterpret_cast<const float2*>(&v);
+        rw[j][1] = f.x; rw[j][2] = f.y;
       } else {
-        typedef typename std::conditional<std::is_same<T, h16_t>::value, CvtH16, CvtB16>::type CV;
-        if constexpr (VEC == 8) {
-          const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
-          const uint4 q = *reinterpret_cast<const uint4*>(&v);
-          rw[j][1] = CV::lo(q.x); rw[j][2] = CV::hi(q.x); rw[j][3] = CV::lo(q.y); rw[j][4] = CV::hi(q.y);
-          rw[j][5] = CV::lo(q.z); rw[j][6] = CV::hi(q.z); rw[j][7] = CV::lo(q.w); rw[j][8] = CV::hi(q.w);
-        } else if constexpr (VEC == 4) {
-          const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
-          const uint2 q = *reinterpret_cast<const uint2*>(&v);
-          rw[j][1] = CV::lo(q.x); rw[j][2] = CV::hi(q.x); rw[j][3] = CV::lo(q.y); rw[j][4] = CV::hi(q.y);
-        } else if constexpr (VEC == 2) {
-          const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
-          rw[j][1] = CV::lo(q); rw[j][2] = CV::hi(q);
-        } else {
-          rw[j][1] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0));
-        }
-        rw[j][0] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vl, so, 0));
-        rw[j][VEC + 1] = CV::lo((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vr, so, 0));
+        rw[j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
       }
+      rw[j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vl, so, 0));
+      rw[j][VEC + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vr, so, 0));
     }
   };
   auto accumulate = [&](int c, float (&rw)[R + 2][VEC + 2]) {
@@ -303,14 +258,16 @@ static int stem_launch(int B, int H, int W, const float* x, const float* w, T* y
   return check_launch("stem_kernel");
 }
 
+// ew_c8.hip: the same stencils over channel-blocked 16-bit tensors
+int stem_fwd_c8(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
+int head_fwd_c8(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
+size_t conv1ch_wgrad_c8_workspace_bytes(int, int, int);
+int conv1ch_wgrad_c8(int, int, int, const void*, int, int, const float*, float*, int, float*, size_t, int, hipStream_t);
+
 int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y_ctotal, int y_coff, int flags,
              const void* mask, int m_ctotal, int m_coff, int dtype, hipStream_t stream) {
-  if (dtype == CODON_BF16)
-    return stem_launch<u16_t>(B, H, W, x, w, (u16_t*)y, y_ctotal, y_coff, flags, (const u16_t*)mask, m_ctotal, m_coff,
-                              stream);
-  if (dtype == CODON_F16)
-    return stem_launch<h16_t>(B, H, W, x, w, (h16_t*)y, y_ctotal, y_coff, flags, (const h16_t*)mask, m_ctotal, m_coff,
-                              stream);
+  if (dtype != CODON_F32)
+    return stem_fwd_c8(B, H, W, x, w, y, y_ctotal, y_coff, flags, mask, m_ctotal, m_coff, dtype, stream);
   return stem_launch<float>(B, H, W, x, w, (float*)y, y_ctotal, y_coff, flags, (const float*)mask, m_ctotal, m_coff,
                             stream);
 }
@@ -361,8 +318,7 @@ static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff
 
 int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
              int dtype, hipStream_t stream) {
-  if (dtype == CODON_BF16) return head_launch<u16_t>(B, H, W, (const u16_t*)x, x_ctotal, x_coff, w, res, y, stream);
-  if (dtype == CODON_F16) return head_launch<h16_t>(B, H, W, (const h16_t*)x, x_ctotal, x_coff, w, res, y, stream);
+  if (dtype != CODON_F32) return head_fwd_c8(B, H, W, x, x_ctotal, x_coff, w, res, y, dtype, stream);
   return head_launch<float>(B, H, W, (const float*)x, x_ctotal, x_coff, w, res, y, stream);
 }
 
@@ -428,15 +384,31 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const T* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float* __restrict__ part,
-                                                                   float* __restrict__ dw, int nparts, int flip,
-                                                                   int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 576) return;
+// Second, fixed-order stage: a workgroup owns 64 of the 576 sums; its 16 thread groups each add a contiguous range
+// of the partial rows, then the 16 group sums are added in order (deterministic).  The round-2 version walked all the
+// rows with 576 threads in three workgroups: 0.63 ms for a 576-value result, longer than the kernel that feeds it.
+__global__ __launch_bounds__(1024) void conv1ch_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                    float* __restrict__ dw, int nparts, int flip) {
+  __shared__ float red[16][64];
+  const int li = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + li;               // 9 workgroups x 64 = 576
+  const int per = (nparts + 15) / 16;
+  const int p0 = g * per, p1 = min(p0 + per, nparts);
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long)p * 576 + i];
-  const int o = flip ? (i / 9) * 9 + 8 - (i % 9) : i;
-  dw[o] = accumulate ? dw[o] + s : s;
+  for (int p = p0; p < p1; ++p) s += part[(long)p * 576 + i];
+  red[g][li] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = red[0][li];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][li];
+    dw[flip ? (i / 9) * 9 + 8 - (i % 9) : i] = t;
+  }
+}
+
+int conv1ch_wgrad_reduce(const float* part, float* dw, int nparts, int flip, hipStream_t stream) {
+  hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(9), dim3(1024), 0, stream, part, dw, nparts, flip);
+  return check_launch("conv1ch_wgrad_reduce_kernel");
 }
 
 size_t conv1ch_wgrad_workspace_bytes(int B, int H, int W) {
@@ -446,23 +418,17 @@ size_t conv1ch_wgrad_workspace_bytes(int B, int H, int W) {
 
 int conv1ch_wgrad(int B, int H, int W, const void* a, int a_ctotal, int a_coff, const float* s, float* dw, int flip,
                   float* ws, size_t ws_bytes, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32)
+    return conv1ch_wgrad_c8(B, H, W, a, a_ctotal, a_coff, s, dw, flip, ws, ws_bytes, dtype, stream);
   CODON_REQUIRE(ws_bytes >= conv1ch_wgrad_workspace_bytes(B, H, W), CODON_ERR_BAD_ARG,
                 "conv1ch_wgrad: workspace too small");
   const long HW = (long)H * W;
   const int nrowblk = (H + W1_ROWS - 1) / W1_ROWS;
-  if (dtype == CODON_F16)
-    hipLaunchKernelGGL(conv1ch_wgrad_kernel<h16_t>, dim3(B * nrowblk), dim3(256), 0, stream, (const h16_t*)a,
-                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
-  else if (dtype == CODON_BF16)
-    hipLaunchKernelGGL(conv1ch_wgrad_kernel<u16_t>, dim3(B * nrowblk), dim3(256), 0, stream, (const u16_t*)a,
-                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
-  else
-    hipLaunchKernelGGL(conv1ch_wgrad_kernel<float>, dim3(B * nrowblk), dim3(256), 0, stream, (const float*)a,
-                       a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
-  int st = check_launch("conv1ch_wgrad_kernel");
+  hipLaunchKernelGGL(conv1ch_wgrad_kernel<float>, dim3(B * nrowblk), dim3(256), 0, stream, (const float*)a,
+                     a_ctotal * HW, a_coff * HW, s, ws, H, W, nrowblk);
+  const int st = check_launch("conv1ch_wgrad_kernel");
   if (st != CODON_OK) return st;
-  hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(3), dim3(256), 0, stream, ws, dw, B * nrowblk, flip, 0);
-  return check_launch("conv1ch_wgrad_reduce_kernel");
+  return conv1ch_wgrad_reduce(ws, dw, B * nrowblk, flip, stream);
 }
 
 }  // namespace codon

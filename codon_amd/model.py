@@ -228,7 +228,7 @@ class _CODONBase(nn.Module):
         B, _, H, W = x.shape
         dev = x.device
         adt = self._act_dtype()
-        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
+        new = lambda c: ops.new_act(B, c, H, W, adt, dev)
         P = self._packed
         keep = save is not None
 
@@ -391,7 +391,7 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape
         adt = self._act_dtype()
-        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=x.device)
+        new = lambda c: ops.new_act(B, c, H, W, adt, x.device)
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
         P = self._packed
         S3, S5 = self._split(3), self._split(5)
@@ -449,7 +449,7 @@ class BaseNet_RMCR_fuseRMCR_cross(_CODONBase):
         B, _, H, W = x.shape
         dev = x.device
         adt = self._act_dtype()
-        new = lambda c: torch.empty((B, c, H, W), dtype=adt, device=dev)
+        new = lambda c: ops.new_act(B, c, H, W, adt, dev)
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
         fz = dict(dtype=torch.float32, device=dev)
         P = self._packed

@@ -31,7 +31,7 @@ def _dev(*ts):
         if not t.is_cuda:
             raise RuntimeError("codon_amd: tensors must live on a HIP device (there is no CPU path)")
         if not t.is_contiguous():
-            raise RuntimeError("codon_amd: tensors must be contiguous NCHW")
+            raise RuntimeError("codon_amd: tensors must be contiguous")
         if d is None:
             d = t.device
         elif t.device != d:
@@ -52,21 +52,65 @@ def _ptr(t: Optional[torch.Tensor]):
 PROFILE = None
 
 
+def is_c8(dtype: torch.dtype) -> bool:
+    """16-bit activations are stored channel-blocked, [B][C/8][H][W][8] (csrc/c8.h); fp32 ones NCHW."""
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+def new_act(B: int, C: int, H: int, W: int, dtype: torch.dtype, device) -> torch.Tensor:
+    """Uninitialised activation buffer of C channels in the layout the kernels use for `dtype`."""
+    if is_c8(dtype):
+        assert C % 8 == 0
+        return torch.empty((B, C // 8, H, W, 8), dtype=dtype, device=device)
+    return torch.empty((B, C, H, W), dtype=dtype, device=device)
+
+
+def from_nchw(t: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """(B,C,H,W) tensor -> activation buffer of `dtype` (a layout change for the 16-bit types; test / tool plumbing)."""
+    dtype = dtype or t.dtype
+    t = t.to(dtype)
+    if not is_c8(dtype):
+        return t.contiguous()
+    B, C, H, W = t.shape
+    return t.reshape(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def to_nchw(buf: torch.Tensor) -> torch.Tensor:
+    """Activation buffer -> (B,C,H,W) tensor (a copy for the channel-blocked 16-bit layout)."""
+    if buf.dim() == 4:
+        return buf
+    B, CB, H, W, _ = buf.shape
+    return buf.permute(0, 1, 4, 2, 3).reshape(B, CB * 8, H, W)
+
+
+def _bhw(buf: torch.Tensor):
+    return buf.shape[0], buf.shape[2], buf.shape[3]
+
+
+def _channels(buf: torch.Tensor) -> int:
+    return buf.shape[1] * 8 if buf.dim() == 5 else buf.shape[1]
+
+
 class Slice:
-    """Channels [coff, coff+c) of a contiguous (B, ctotal, H, W) buffer."""
+    """Channels [coff, coff+c) of an activation buffer: contiguous (B, ctotal, H, W) for fp32, channel-blocked
+    (B, ctotal/8, H, W, 8) for bf16 / fp16 (then coff and c are multiples of 8)."""
     __slots__ = ("buf", "coff", "c")
 
     def __init__(self, buf: torch.Tensor, coff: int = 0, c: Optional[int] = None):
         self.buf, self.coff = buf, coff
-        self.c = buf.shape[1] - coff if c is None else c
-        assert 0 <= coff and coff + self.c <= buf.shape[1]
+        self.c = _channels(buf) - coff if c is None else c
+        assert 0 <= coff and coff + self.c <= _channels(buf)
+        assert buf.dim() == 4 or (buf.dim() == 5 and buf.shape[4] == 8 and is_c8(buf.dtype) and coff % 8 == 0
+                                  and self.c % 8 == 0)
+        assert buf.dim() == 5 or not is_c8(buf.dtype), "16-bit activations must be channel-blocked (ops.from_nchw)"
 
     @property
     def ctotal(self):
-        return self.buf.shape[1]
+        return _channels(self.buf)
 
     def view(self):
-        return self.buf[:, self.coff:self.coff + self.c]
+        """The slice as a (B,c,H,W) tensor (a copy for the channel-blocked layout)."""
+        return to_nchw(self.buf)[:, self.coff:self.coff + self.c]
 
     def ct(self):
         return L.Tensor(self.buf.data_ptr(), self.ctotal, self.coff)
@@ -97,8 +141,8 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
         residual = relu_mask
     lib = L.load()
     dev = _dev(x.buf, w_packed, y.buf, residual.buf if residual else None)
-    B, _, H, W = x.buf.shape
-    assert y.buf.shape[0] == B and y.buf.shape[2:] == x.buf.shape[2:]
+    B, H, W = _bhw(x.buf)
+    assert _bhw(y.buf) == (B, H, W)
     flags = (L.CONV_RELU if relu else 0) | (L.CONV_ACCUM_OUT if accumulate else 0) | (L.CONV_F16X3 if f16x3 else 0)
     if relu_mask is not None:
         flags |= L.CONV_MASK_RELU
@@ -107,7 +151,7 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
     d = L.ConvDesc(B, H, W, x.c, y.c, ksize, x.ctotal, x.coff, y.ctotal, y.coff,
                    residual.ctotal if residual else 0, residual.coff if residual else 0, flags, _dt(x.buf))
     if residual is not None:
-        assert residual.c == y.c and residual.buf.shape[2:] == x.buf.shape[2:]
+        assert residual.c == y.c and _bhw(residual.buf) == (B, H, W)
     prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
     with torch.cuda.device(dev):
         if prof is not None:
@@ -126,10 +170,10 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
     mid, when given, also receives relu(conv5x5(x)) (training saves it)."""
     lib = L.load()
     dev = _dev(x.buf, w_packed, w_chain, out.buf, mid.buf if mid else None, residual.buf if residual else None)
-    B, _, H, W = x.buf.shape
-    assert out.c == 64 and out.buf.shape[0] == B and out.buf.shape[2:] == x.buf.shape[2:]
-    assert out.buf.dtype == x.buf.dtype and (mid is None or (mid.c == 128 and mid.buf.shape[2:] == x.buf.shape[2:]))
-    assert residual is None or (residual.c == 64 and residual.buf.shape[2:] == x.buf.shape[2:])
+    B, H, W = _bhw(x.buf)
+    assert out.c == 64 and _bhw(out.buf) == (B, H, W)
+    assert out.buf.dtype == x.buf.dtype and (mid is None or (mid.c == 128 and _bhw(mid.buf) == (B, H, W)))
+    assert residual is None or (residual.c == 64 and _bhw(residual.buf) == (B, H, W))
     flags = L.CONV_RELU | (L.CONV_F16X3 if f16x3 else 0)
     d = L.ConvDesc(B, H, W, x.c, 128, 5, x.ctotal, x.coff, mid.ctotal if mid else 128, mid.coff if mid else 0,
                    0, 0, flags, _dt(x.buf))
@@ -153,8 +197,8 @@ def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, 
     """y = conv(pre * (ch * sp) + inputs) [relu]: the CAC gate-apply of the producing block formed while staging."""
     lib = L.load()
     dev = _dev(pre.buf, inputs.buf, ch, sp, w_packed, y.buf)
-    B, _, H, W = pre.buf.shape
-    assert inputs.c == pre.c and inputs.buf.shape == pre.buf.shape[:1] + inputs.buf.shape[1:2] + pre.buf.shape[2:]
+    B, H, W = _bhw(pre.buf)
+    assert inputs.c == pre.c and _bhw(inputs.buf) == (B, H, W)
     assert ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64) and ch.is_contiguous()
     assert sp.dtype == torch.float32 and tuple(sp.shape) == (B, 1, H, W) and sp.is_contiguous()
     d = L.ConvDesc(B, H, W, pre.c, y.c, ksize, pre.ctotal, pre.coff, y.ctotal, y.coff, 0, 0,
@@ -169,7 +213,7 @@ def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: 
     """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy."""
     lib = L.load()
     dev = _dev(x.buf, gy.buf, dw)
-    B, _, H, W = x.buf.shape
+    B, H, W = _bhw(x.buf)
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, ksize, ksize)
     d = L.ConvDesc(B, H, W, x.c, gy.c, ksize, x.ctotal, x.coff, gy.ctotal, gy.coff, 0, 0, 0, _dt(x.buf))
     nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
@@ -194,7 +238,7 @@ def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
 def head(x: Slice, w: torch.Tensor, residual: torch.Tensor, y: torch.Tensor):
     lib = L.load()
     dev = _dev(x.buf, w, residual, y)
-    B, _, H, W = x.buf.shape
+    B, H, W = _bhw(x.buf)
     assert x.c == 64 and w.dtype == torch.float32 and residual.dtype == torch.float32 and y.dtype == torch.float32
     with torch.cuda.device(dev):
         L.check(lib.codon_head_fwd(B, H, W, _ptr(x.buf), x.ctotal, x.coff, _ptr(w), _ptr(residual), _ptr(y),
@@ -208,7 +252,7 @@ def cac_stats_tiles(H: int, W: int) -> int:
 def cac_stats(pre_c: Slice, pre: Slice, pooled: torch.Tensor, partials: torch.Tensor):
     lib = L.load()
     dev = _dev(pre_c.buf, pre.buf, pooled, partials)
-    B, _, H, W = pre.buf.shape
+    B, H, W = _bhw(pre.buf)
     a, b = pre_c.ct(), pre.ct()
     with torch.cuda.device(dev):
         L.check(lib.codon_cac_stats_fwd(B, H, W, C.byref(a), C.byref(b), _ptr(pooled), _ptr(partials),
@@ -219,7 +263,7 @@ def cac_stats_scaled(pre_c: Slice, pre: Slice, ch: torch.Tensor, pooled: torch.T
     """ChannelPool of the channel-gated features (Fcat * ch): the spatial gate's input in the sequential-gate ablation."""
     lib = L.load()
     dev = _dev(pre_c.buf, pre.buf, ch, pooled, partials)
-    B, _, H, W = pre.buf.shape
+    B, H, W = _bhw(pre.buf)
     assert ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
     a, b = pre_c.ct(), pre.ct()
     with torch.cuda.device(dev):
@@ -231,7 +275,7 @@ def ew_sq_scale(x: Slice, ch: torch.Tensor, y: Slice):
     """y = x * x * ch[b][c] (64-channel slices)."""
     lib = L.load()
     dev = _dev(x.buf, ch, y.buf)
-    B, _, H, W = x.buf.shape
+    B, H, W = _bhw(x.buf)
     assert x.c == 64 and y.c == 64 and ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
     xt, yt = x.ct(), y.ct()
     with torch.cuda.device(dev):
@@ -261,7 +305,7 @@ def cac_spatial(pooled: torch.Tensor, w: torch.Tensor, sp: torch.Tensor):
 def cac_apply(pre: Slice, pre_c: Slice, ch, sp, inputs: Slice, inputs_c: Slice, out: Slice, out_c: Slice):
     lib = L.load()
     dev = _dev(pre.buf, pre_c.buf, ch, sp, inputs.buf, inputs_c.buf, out.buf, out_c.buf)
-    B, _, H, W = pre.buf.shape
+    B, H, W = _bhw(pre.buf)
     ts = [s.ct() for s in (pre, pre_c, inputs, inputs_c, out, out_c)]
     with torch.cuda.device(dev):
         L.check(lib.codon_cac_apply_fwd(B, H, W, C.byref(ts[0]), C.byref(ts[1]), _ptr(ch), _ptr(sp),
@@ -288,7 +332,7 @@ def stencil_1to64(x: torch.Tensor, w: torch.Tensor, y: Slice, relu: bool = False
 def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: torch.Tensor, flip: bool):
     lib = L.load()
     dev = _dev(a.buf, s, dw)
-    B, _, H, W = a.buf.shape
+    B, H, W = _bhw(a.buf)
     assert a.c == 64 and dw.numel() == 576 and dw.dtype == torch.float32 and s.shape[1] == 1
     nbytes = lib.codon_conv1ch_wgrad_workspace_bytes(B, H, W)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
@@ -301,7 +345,7 @@ def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: torch.Tensor, flip: bool):
 def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] = None, accumulate: bool = True):
     lib = L.load()
     dev = _dev(dst.buf, src.buf if src else None, mask.buf if mask else None)
-    B, _, H, W = dst.buf.shape
+    B, H, W = _bhw(dst.buf)
     dt_, st_, mt_ = dst.ct(), (src.ct() if src else None), (mask.ct() if mask else None)
     with torch.cuda.device(dev):
         L.check(lib.codon_ew_add_mask(B, H, W, dst.c, C.byref(dt_), C.byref(st_) if st_ is not None else None,
@@ -315,7 +359,7 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
     lib = L.load()
     dev = _dev(g_out.buf, g_out_c.buf, pre.buf, pre_c.buf, ch, sp, pooled, pools, w1, b1, w2, ws, g_pre.buf,
                g_pre_c.buf, g_in.buf, g_in_c.buf)
-    B, _, H, W = pre.buf.shape
+    B, H, W = _bhw(pre.buf)
     f32 = dict(dtype=torch.float32, device=dev)
     nt = lib.codon_cac_bwd_tiles(H, W)
     nsb = lib.codon_cac_bwd_spatial_blocks(B, H, W)

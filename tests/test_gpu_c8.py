@@ -1,0 +1,212 @@
+"""Channel-blocked 16-bit kernels (codon_amd/csrc/{ew_c8,conv_c8,conv_wgrad_c8}.hip) against the fp32 NCHW kernels of
+the same entry points on the SAME values (inputs rounded to bf16 / fp16 first, so the two paths see identical operands
+and differ only by the 16-bit rounding of what they store).  The fp32 kernels themselves are pinned to torch / the oracle
+in test_gpu_kernels.py and test_gpu_backward.py.  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import rel_rmse, rmse
+
+DT = [torch.bfloat16, torch.float16]
+SHAPES = [(2, 19, 45), (1, 1, 1), (1, 33, 70), (2, 64, 40), (1, 5, 3)]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(size=shape) * scale).astype(np.float32))
+
+
+def _tol(dtype):
+    return 4e-3 if dtype == torch.bfloat16 else 6e-4
+
+
+def test_layout_round_trip_and_addressing():
+    """ops.from_nchw / to_nchw state the layout of csrc/c8.h: element (b,c,h,w) at (((b*C/8 + c/8)*H + h)*W + w)*8 + c%8."""
+    from codon_amd import ops
+    B, C, H, W = 2, 24, 3, 5
+    t = torch.arange(B * C * H * W, dtype=torch.float32).reshape(B, C, H, W) % 251
+    buf = ops.from_nchw(t, torch.bfloat16)
+    assert tuple(buf.shape) == (B, C // 8, H, W, 8) and buf.is_contiguous()
+    flat = buf.flatten()
+    for (b, c, h, w) in [(0, 0, 0, 0), (1, 23, 2, 4), (0, 9, 1, 3), (1, 8, 0, 0)]:
+        assert float(flat[(((b * (C // 8) + c // 8) * H + h) * W + w) * 8 + c % 8]) == float(t[b, c, h, w])
+    assert torch.equal(ops.to_nchw(buf).float(), t)
+    s = ops.Slice(buf, 8, 16)
+    assert s.ctotal == 24 and torch.equal(s.view().float(), t[:, 8:24])
+    with pytest.raises(AssertionError):
+        ops.Slice(buf, 4, 8)                       # slices start on a plane boundary
+    with pytest.raises(AssertionError):
+        ops.Slice(t.bfloat16())                    # an NCHW 16-bit tensor is not an activation buffer
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_stem_and_masked_flipped_stencil(shape, dtype):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, 1, H, W), 1).to(dev)
+    w = _rand((64, 1, 3, 3), 2, 0.3).to(dev)
+    mask = _rand((B, 64, H, W), 3).to(dtype).float().to(dev)
+    for relu, flip, use_mask in [(True, False, False), (False, True, True), (False, False, True)]:
+        ref = torch.empty((B, 128, H, W), device=dev)
+        ops.stencil_1to64(x, w, Slice(ref, 64, 64), relu=relu, flip=flip, mask=Slice(mask) if use_mask else None)
+        out = ops.new_act(B, 128, H, W, dtype, dev).fill_(float("nan"))
+        ops.stencil_1to64(x, w, Slice(out, 64, 64), relu=relu, flip=flip,
+                          mask=Slice(ops.from_nchw(mask, dtype)) if use_mask else None)
+        o = ops.to_nchw(out).float()
+        assert torch.isnan(o[:, :64]).all()
+        assert torch.equal(o[:, 64:], ref[:, 64:].to(dtype).float())       # same fp32 arithmetic, one rounding
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", SHAPES + [(1, 40, 130)])
+def test_head_and_conv1ch_wgrad(shape, dtype):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    f = _rand((B, 128, H, W), 3).to(dtype).float().to(dev)
+    wo = _rand((1, 64, 3, 3), 4, 0.1).to(dev)
+    res = _rand((B, 1, H, W), 5).to(dev)
+    ref = torch.empty((B, 1, H, W), device=dev)
+    ops.head(Slice(f, 64, 64), wo, res, ref)
+    out = torch.full((B, 1, H, W), float("nan"), device=dev)
+    ops.head(Slice(ops.from_nchw(f, dtype), 64, 64), wo, res, out)
+    assert rel_rmse(out.cpu(), ref.cpu()) < 2e-6               # fp32 math on identical operands: summation order only
+    tref = F.conv2d(f[:, 64:].cpu(), wo.cpu(), None, 1, 1) + res.cpu()
+    assert rel_rmse(out.cpu(), tref) < 2e-6
+    s = _rand((B, 1, H, W), 6).to(dev)
+    for flip in (False, True):
+        d0, d1 = torch.empty(576, device=dev), torch.full((576,), float("nan"), device=dev)
+        ops.conv1ch_wgrad(Slice(f, 0, 64), s, d0, flip=flip)
+        ops.conv1ch_wgrad(Slice(ops.from_nchw(f, dtype), 0, 64), s, d1, flip=flip)
+        assert rel_rmse(d1.cpu(), d0.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_cac_forward_passes(shape, dtype):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    pre2 = _rand((B, 128, H, W), 5).to(dtype).float().to(dev)
+    in2 = _rand((B, 128, H, W), 6).to(dtype).float().to(dev)
+    p16, i16 = ops.from_nchw(pre2, dtype), ops.from_nchw(in2, dtype)
+    chs = torch.rand((B, 64), device=dev)
+    nt = ops.cac_stats_tiles(H, W)
+    mk = lambda: (torch.empty((B, 2, H, W), device=dev), torch.empty((B, nt, 128, 2), device=dev))
+    for scaled in (False, True):
+        (po0, pa0), (po1, pa1) = mk(), mk()
+        if scaled:
+            ops.cac_stats_scaled(Slice(pre2, 64, 64), Slice(pre2, 0, 64), chs, po0, pa0)
+            ops.cac_stats_scaled(Slice(p16, 64, 64), Slice(p16, 0, 64), chs, po1, pa1)
+        else:
+            ops.cac_stats(Slice(pre2, 64, 64), Slice(pre2, 0, 64), po0, pa0)
+            ops.cac_stats(Slice(p16, 64, 64), Slice(p16, 0, 64), po1, pa1)
+        assert torch.equal(po1[:, 0], po0[:, 0])                             # channel max: exact
+        assert rmse(po1[:, 1].cpu(), po0[:, 1].cpu()) < 1e-6                 # channel mean: summation order
+        assert torch.equal(pa1[..., 1], pa0[..., 1])                         # per-tile channel maxima: exact
+        assert rel_rmse(pa1[..., 0].cpu(), pa0[..., 0].cpu()) < 1e-5
+    ch = torch.rand((B, 64), device=dev)
+    sp = torch.rand((B, 1, H, W), device=dev)
+    oc0 = torch.empty((B, 128, H, W), device=dev)
+    oc1 = ops.new_act(B, 128, H, W, dtype, dev)
+    ops.cac_apply(Slice(pre2, 0, 64), Slice(pre2, 64, 64), ch, sp, Slice(in2, 0, 64), Slice(in2, 64, 64),
+                  Slice(oc0, 0, 64), Slice(oc0, 64, 64))
+    ops.cac_apply(Slice(p16, 0, 64), Slice(p16, 64, 64), ch, sp, Slice(i16, 0, 64), Slice(i16, 64, 64),
+                  Slice(oc1, 0, 64), Slice(oc1, 64, 64))
+    assert torch.equal(ops.to_nchw(oc1).float(), oc0.to(dtype).float())
+    y0, y1 = torch.empty((B, 64, H, W), device=dev), ops.new_act(B, 64, H, W, dtype, dev)
+    ops.ew_sq_scale(Slice(pre2, 64, 64), ch, Slice(y0))
+    ops.ew_sq_scale(Slice(p16, 64, 64), ch, Slice(y1))
+    assert torch.equal(ops.to_nchw(y1).float(), y0.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 33, 70)])
+def test_ew_add_mask(shape, dtype):
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    q = lambda seed: _rand((B, 128, H, W), seed).to(dtype).float().to(dev)
+    for (C, use_src, use_mask, acc) in [(64, True, False, True), (128, False, True, True), (64, True, True, False)]:
+        d0, s0, m0 = q(1), q(2), q(3)
+        d1, s1, m1 = (ops.from_nchw(t, dtype) for t in (d0, s0, m0))
+        ops.ew_add_mask(Slice(d0, 128 - C, C), Slice(s0, 0, C) if use_src else None, Slice(m0, 0, C) if use_mask else None,
+                        accumulate=acc)
+        ops.ew_add_mask(Slice(d1, 128 - C, C), Slice(s1, 0, C) if use_src else None, Slice(m1, 0, C) if use_mask else None,
+                        accumulate=acc)
+        assert torch.equal(ops.to_nchw(d1).float(), d0.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 50, 70)])
+@pytest.mark.parametrize("accumulate_in", [False, True])
+def test_cac_backward(shape, dtype, accumulate_in):
+    """All four CAC backward launches on blocked tensors vs the fp32 kernels on the same 16-bit-representable values:
+    arg-max routing of both max-pools and of the channel max must pick the same elements (ties included: values are
+    16-bit, so exact ties across channels and pixels are common)."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    q = lambda seed, s=1.0: _rand((B, 128, H, W), seed, s).to(dtype).float().to(dev)
+    g_oc, pre2, g_in = q(1, 0.1), q(2), q(3, 0.1)
+    w1, b1, w2 = _rand((8, 128), 7, 0.1).to(dev), _rand((8,), 8, 0.1).to(dev), _rand((64, 8), 9, 0.3).to(dev)
+    b2, ws = _rand((64,), 10, 0.1).to(dev), _rand((1, 2, 5, 5), 11, 0.2).to(dev)
+    nt = ops.cac_stats_tiles(H, W)
+    pooled, partials = torch.empty((B, 2, H, W), device=dev), torch.empty((B, nt, 128, 2), device=dev)
+    ch, sp, pools = torch.empty((B, 64), device=dev), torch.empty((B, 1, H, W), device=dev), torch.empty((B, 2, 128), device=dev)
+    ops.cac_stats(Slice(pre2, 64, 64), Slice(pre2, 0, 64), pooled, partials)
+    ops.cac_gate(B, H, W, partials, w1, b1, w2, b2, ch, pools)
+    ops.cac_spatial(pooled, ws, sp)
+
+    def run(conv):
+        go, pr, gi = conv(g_oc), conv(pre2), conv(g_in)
+        gp = torch.full_like(go, float("nan"))
+        outs = ops.cac_backward(Slice(go, 0, 64), Slice(go, 64, 64), Slice(pr, 0, 64), Slice(pr, 64, 64), ch, sp, pooled,
+                                pools, w1, b1, w2, ws, Slice(gp, 0, 64), Slice(gp, 64, 64), Slice(gi, 0, 64),
+                                Slice(gi, 64, 64), accumulate_in=accumulate_in)
+        return outs, ops.to_nchw(gp).float(), ops.to_nchw(gi).float()
+
+    outs0, gp0, gi0 = run(lambda t: t.clone())
+    outs1, gp1, gi1 = run(lambda t: ops.from_nchw(t, dtype))
+    for a, b in zip(outs1, outs0):                                   # parameter gradients: fp32 either way
+        assert rel_rmse(a.cpu(), b.cpu()) < 2e-5
+    assert rel_rmse(gp1.cpu(), gp0.cpu()) < _tol(dtype)
+    # routing: the few large entries (arg-max pixels / channels) are where a wrong choice would show
+    assert float((gp1 - gp0).abs().max()) <= 2 * _tol(dtype) * float(gp0.abs().max())
+    assert torch.equal(gi1, gi0.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_dgrad_and_1x1_against_fp32_kernels(dtype):
+    """PACK_DGRAD weights + MASK_RELU / ACCUM_OUT epilogues and the stand-alone 1x1 (both directions), blocked vs fp32."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 21, 37
+    for (k, cin, cout) in [(5, 128, 128), (5, 64, 64), (3, 64, 64), (3, 128, 64), (1, 128, 64)]:
+        w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5).to(dtype).float().to(dev)
+        gy = _rand((B, cout, H, W), 3).to(dtype).float().to(dev)
+        act = _rand((B, cin, H, W), 4).to(dtype).float().to(dev)
+        prev = _rand((B, cin, H, W), 5).to(dtype).float().to(dev)
+        g0 = prev.clone()
+        ops.conv2d(Slice(gy), ops.packed_weight(w, L.PACK_DGRAD), Slice(g0), k, relu_mask=Slice(act), accumulate=True)
+        g1 = ops.from_nchw(prev, dtype)
+        ops.conv2d(Slice(ops.from_nchw(gy, dtype)), ops.packed_weight(w, L.PACK_DGRAD, dtype), Slice(g1), k,
+                   relu_mask=Slice(ops.from_nchw(act, dtype)), accumulate=True)
+        assert rel_rmse(ops.to_nchw(g1).float().cpu(), g0.cpu()) < _tol(dtype), (k, cin, cout)

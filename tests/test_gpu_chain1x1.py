@@ -65,26 +65,27 @@ def test_chain1x1_16bit(shape, dtype):
     q = lambda t: t.to(dtype).float()
     mid_ref = q(F.relu(F.conv2d(q(x), q(w5), None, 1, 2)))
     out_ref = F.conv2d(mid_ref, q(w1)) + q(r)
-    xd, rd = x.to(dev).to(dtype), r.to(dev).to(dtype)
+    xd, rd = ops.from_nchw(x.to(dev), dtype), ops.from_nchw(r.to(dev), dtype)      # channel-blocked 16-bit buffers
     wp = ops.packed_weight(w5.to(dev), L.PACK_FWD, dtype)
     wc = ops.packed_weight(w1.to(dev), L.PACK_CHAIN1X1, dtype)
-    mid = torch.full((B, 128, H, W), float("nan"), device=dev, dtype=dtype)
-    out = torch.full((B, 128, H, W), float("nan"), device=dev, dtype=dtype)
+    nan = lambda c: ops.new_act(B, c, H, W, dtype, dev).fill_(float("nan"))
+    nchw = lambda buf: ops.to_nchw(buf).float().cpu()
+    mid, out = nan(128), nan(128)
     ops.conv_chain1x1(Slice(xd), wp, wc, Slice(out, 0, 64), mid=Slice(mid), residual=Slice(rd))
-    assert torch.isnan(out[:, 64:]).all()
+    assert torch.isnan(nchw(out)[:, 64:]).all()
     tol = 6e-3 if dtype == torch.bfloat16 else 8e-4
-    assert rel_rmse(out[:, :64].float().cpu(), out_ref) < tol
-    assert rel_rmse(mid.float().cpu(), mid_ref) < tol
+    assert rel_rmse(nchw(out)[:, :64], out_ref) < tol
+    assert rel_rmse(nchw(mid), mid_ref) < tol
     m2 = torch.empty_like(mid)
     ops.conv2d(Slice(xd), wp, Slice(m2), 5, relu=True)
     assert torch.equal(m2, mid)
-    o3 = torch.empty((B, 64, H, W), device=dev, dtype=dtype)
+    o3 = nan(64)
     ops.conv2d(Slice(m2), ops.packed_weight(w1.to(dev), L.PACK_FWD, dtype), Slice(o3), 1, residual=Slice(rd))
-    assert rel_rmse(out[:, :64].float().cpu(), o3.float().cpu()) < tol
+    assert rel_rmse(nchw(out)[:, :64], nchw(o3)) < tol
     # without the intermediate
-    o4 = torch.empty((B, 64, H, W), device=dev, dtype=dtype)
+    o4 = nan(64)
     ops.conv_chain1x1(Slice(xd), wp, wc, Slice(o4), residual=Slice(rd))
-    assert torch.equal(o4, out[:, :64])
+    assert torch.equal(ops.to_nchw(o4), ops.to_nchw(out)[:, :64])
 
 
 @pytest.mark.parametrize("shape", SHAPES)

@@ -20,6 +20,25 @@ def _rand(shape, seed, scale=1.0):
     return torch.from_numpy((g.standard_normal(size=shape) * scale).astype(np.float32))
 
 
+def _act(t, dev):
+    """(B,C,H,W) CPU tensor -> device activation buffer in the layout the kernels use for its dtype (16-bit:
+    channel-blocked, codon_amd/csrc/c8.h)."""
+    from codon_amd import ops
+    return ops.from_nchw(t.to(dev))
+
+
+def _new(B, C, H, W, dtype, dev):
+    from codon_amd import ops
+    buf = ops.new_act(B, C, H, W, dtype, dev)
+    buf.fill_(float("nan"))
+    return buf
+
+
+def _nchw(buf):
+    from codon_amd import ops
+    return ops.to_nchw(buf).float().cpu()
+
+
 CONV_CASES = [  # (k, cin, cout)
     (5, 128, 128), (5, 64, 64), (3, 64, 64), (3, 128, 64), (1, 128, 64), (3, 64, 128), (1, 64, 128),
 ]
@@ -199,7 +218,7 @@ def test_conv2d_wgrad_slices_and_bands():
     w = torch.zeros((64, 64, 5, 5), requires_grad=True)
     F.conv2d(xb[:, 64:], w, None, 1, 2).backward(gb[:, :64])
     dw = torch.empty((64, 64, 5, 5), device=dev)
-    ops.conv2d_wgrad(Slice(xb.to(dev), 64, 64), Slice(gb.to(dev), 0, 64), dw, 5)
+    ops.conv2d_wgrad(Slice(_act(xb, dev), 64, 64), Slice(_act(gb, dev), 0, 64), dw, 5)
     assert rel_rmse(dw.cpu(), w.grad) < 3e-6
 
 
@@ -239,14 +258,38 @@ def test_conv2d_bf16_vs_torch(k, cin, cout, shape):
     w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5)
     ref = F.conv2d(x.float(), w.bfloat16().float(), None, 1, k // 2)     # same operand rounding, fp32 accumulate
     wp = ops.packed_weight(w.to(dev), dtype=torch.bfloat16)
-    y = torch.full((B, cout, H, W), float("nan"), device=dev, dtype=torch.bfloat16)
-    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k)
-    assert rel_rmse(y.float().cpu(), ref) < 3e-3            # only the output rounding to bf16 differs
+    y = _new(B, cout, H, W, torch.bfloat16, dev)
+    xd = _act(x, dev)
+    ops.conv2d(Slice(xd), wp, Slice(y), k)
+    assert rel_rmse(_nchw(y), ref) < 3e-3            # only the output rounding to bf16 differs
     r = _rand((B, cout, H, W), 3).bfloat16()
-    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, relu=True)
-    assert rel_rmse(y.float().cpu(), F.relu(ref)) < 3e-3
-    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, residual=Slice(r.to(dev)))
-    assert rel_rmse(y.float().cpu(), ref + r.float()) < 3e-3
+    ops.conv2d(Slice(xd), wp, Slice(y), k, relu=True)
+    assert rel_rmse(_nchw(y), F.relu(ref)) < 3e-3
+    ops.conv2d(Slice(xd), wp, Slice(y), k, residual=Slice(_act(r, dev)))
+    assert rel_rmse(_nchw(y), ref + r.float()) < 3e-3
+    # backward epilogues: ReLU mask of the tensor the gradient flows into, then fan-in accumulate
+    ops.conv2d(Slice(xd), wp, Slice(y), k, relu_mask=Slice(_act(r, dev)))
+    masked = torch.where(r.float() > 0, ref, torch.zeros_like(ref))
+    assert rel_rmse(_nchw(y), masked) < 3e-3
+    ops.conv2d(Slice(xd), wp, Slice(y), k, accumulate=True)
+    assert rel_rmse(_nchw(y), masked.bfloat16().float() + ref) < 4e-3
+
+
+def test_conv2d_bf16_channel_slices():
+    """Slices of wider channel-blocked buffers (how the torch.cat calls of CODON_x4.py:79,80,119 disappear)."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 21, 37
+    xb = _rand((B, 128, H, W), 1).bfloat16()
+    w = _rand((64, 64, 3, 3), 2, scale=0.06)
+    wp = ops.packed_weight(w.to(dev), dtype=torch.bfloat16)
+    yb = _new(B, 128, H, W, torch.bfloat16, dev)
+    yb.zero_()
+    ops.conv2d(Slice(_act(xb, dev), 64, 64), wp, Slice(yb, 64, 64), 3, relu=True)
+    ref = F.relu(F.conv2d(xb[:, 64:].float(), w.bfloat16().float(), None, 1, 1))
+    out = _nchw(yb)
+    assert rel_rmse(out[:, 64:], ref) < 3e-3 and float(out[:, :64].abs().max()) == 0.0
 
 
 def test_bf16_elementwise_kernels():
@@ -257,13 +300,13 @@ def test_bf16_elementwise_kernels():
     for (B, H, W) in [(2, 16, 24), (1, 19, 45), (1, 1, 1)]:
         x = _rand((B, 1, H, W), 1)
         w = _rand((64, 1, 3, 3), 2, 0.3)
-        y = torch.empty((B, 64, H, W), device=dev, dtype=torch.bfloat16)
+        y = _new(B, 64, H, W, torch.bfloat16, dev)
         ops.stem(x.to(dev), w.to(dev), Slice(y))
-        assert rel_rmse(y.float().cpu(), F.relu(F.conv2d(x, w, None, 1, 1))) < 3e-3
+        assert rel_rmse(_nchw(y), F.relu(F.conv2d(x, w, None, 1, 1))) < 3e-3
         f = _rand((B, 64, H, W), 3).bfloat16()
         wo = _rand((1, 64, 3, 3), 4, 0.1)
         o = torch.empty((B, 1, H, W), device=dev)
-        ops.head(Slice(f.to(dev)), wo.to(dev), x.to(dev), o)
+        ops.head(Slice(_act(f, dev)), wo.to(dev), x.to(dev), o)
         assert rel_rmse(o.cpu(), F.conv2d(f.float(), wo, None, 1, 1) + x) < 1e-5
         pre2 = _rand((B, 128, H, W), 5).bfloat16()
         in2 = _rand((B, 128, H, W), 6).bfloat16()
@@ -273,7 +316,7 @@ def test_bf16_elementwise_kernels():
         Fcat = torch.cat((pre_c, pre), 1)
         ch_ref, sp_ref = orc.cac_channel(Fcat, w1, b1, w2, b2), orc.cac_spatial(Fcat, ws)
         g = ch_ref[:, :, None, None] * sp_ref
-        p2, i2 = pre2.to(dev), in2.to(dev)
+        p2, i2 = _act(pre2, dev), _act(in2, dev)
         nt = ops.cac_stats_tiles(H, W)
         pooled = torch.empty((B, 2, H, W), device=dev); partials = torch.empty((B, nt, 128, 2), device=dev)
         ch = torch.empty((B, 64), device=dev); sp = torch.empty((B, 1, H, W), device=dev)
@@ -282,11 +325,12 @@ def test_bf16_elementwise_kernels():
         ops.cac_gate(B, H, W, partials, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), ch, None)
         ops.cac_spatial(pooled, ws.to(dev), sp)
         assert rmse(ch.cpu(), ch_ref) < 1e-6 and rmse(sp.cpu(), sp_ref) < 1e-6
-        oc = torch.empty((B, 128, H, W), device=dev, dtype=torch.bfloat16)
+        oc = _new(B, 128, H, W, torch.bfloat16, dev)
         ops.cac_apply(Slice(p2, 0, 64), Slice(p2, 64, 64), ch, sp, Slice(i2, 0, 64), Slice(i2, 64, 64),
                       Slice(oc, 0, 64), Slice(oc, 64, 64))
-        assert rel_rmse(oc[:, :64].float().cpu(), pre * g + in2[:, :64].float()) < 3e-3
-        assert rel_rmse(oc[:, 64:].float().cpu(), pre_c * g + in2[:, 64:].float()) < 3e-3
+        ocn = _nchw(oc)
+        assert rel_rmse(ocn[:, :64], pre * g + in2[:, :64].float()) < 3e-3
+        assert rel_rmse(ocn[:, 64:], pre_c * g + in2[:, 64:].float()) < 3e-3
 
 
 @pytest.mark.parametrize("k,cin,cout", WGRAD_CASES)
@@ -301,14 +345,14 @@ def test_conv2d_wgrad_bf16_vs_autograd(k, cin, cout, shape):
     w = torch.zeros((cout, cin, k, k), requires_grad=True)
     F.conv2d(x.float(), w, None, 1, k // 2).backward(gy.float())      # same bf16-rounded operands, fp32 math
     dw = torch.full((cout, cin, k, k), float("nan"), device=dev)
-    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k)
+    ops.conv2d_wgrad(Slice(_act(x, dev)), Slice(_act(gy, dev)), dw, k)
     assert dw.dtype == torch.float32
     assert rel_rmse(dw.cpu(), w.grad) < 1e-5        # fp32 accumulate: only summation order differs
-    ops.conv2d_wgrad(Slice(x.to(dev)), Slice(gy.to(dev)), dw, k, accumulate=True)
+    ops.conv2d_wgrad(Slice(_act(x, dev)), Slice(_act(gy, dev)), dw, k, accumulate=True)
     assert rel_rmse(dw.cpu(), 2 * w.grad) < 1e-5
 
 
-@pytest.mark.parametrize("W", [37, 40])       # 37: pixel-major fallback kernel; 40: channel-major kernel (W % 8 == 0)
+@pytest.mark.parametrize("W", [37, 40])
 def test_conv2d_wgrad_bf16_slices(W):
     from codon_amd import ops
     from codon_amd.ops import Slice
@@ -319,7 +363,7 @@ def test_conv2d_wgrad_bf16_slices(W):
     w = torch.zeros((64, 64, 5, 5), requires_grad=True)
     F.conv2d(xb[:, 64:].float(), w, None, 1, 2).backward(gb[:, :64].float())
     dw = torch.empty((64, 64, 5, 5), device=dev)
-    ops.conv2d_wgrad(Slice(xb.to(dev), 64, 64), Slice(gb.to(dev), 0, 64), dw, 5)
+    ops.conv2d_wgrad(Slice(_act(xb, dev), 64, 64), Slice(_act(gb, dev), 0, 64), dw, 5)
     assert rel_rmse(dw.cpu(), w.grad) < 1e-5
 
 
@@ -333,9 +377,9 @@ def test_conv2d_fp16_vs_torch(k, cin, cout):
     w = _rand((cout, cin, k, k), 2, scale=(2.0 / (k * k * cout)) ** 0.5)
     ref = F.conv2d(x.float(), w.half().float(), None, 1, k // 2)
     wp = ops.packed_weight(w.to(dev), dtype=torch.float16)
-    y = torch.full((B, cout, H, W), float("nan"), device=dev, dtype=torch.float16)
-    ops.conv2d(Slice(x.to(dev)), wp, Slice(y), k, relu=True)
-    assert rel_rmse(y.float().cpu(), F.relu(ref)) < 5e-4
+    y = _new(B, cout, H, W, torch.float16, dev)
+    ops.conv2d(Slice(_act(x, dev)), wp, Slice(y), k, relu=True)
+    assert rel_rmse(_nchw(y), F.relu(ref)) < 5e-4
 
 
 def test_conv2d_plane_larger_than_32bit_slice():
