@@ -20,6 +20,7 @@ OK = 0
 F32, BF16, F16 = 0, 1, 2
 CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU, CONV_F16X3 = 1, 2, 4, 8, 16
 PACK_FWD, PACK_DGRAD, PACK_FWD_F16X3, PACK_CHAIN1X1, PACK_CHAIN1X1_F16X3 = 0, 1, 2, 3, 4
+CAC_FOLDS = 16   # CODON_CAC_FOLDS
 
 
 class ConvDesc(C.Structure):
@@ -44,6 +45,10 @@ SIGNATURES = {
     "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "codon_conv_chain1x1_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P]),
+    "codon_conv_chain1x1_stats_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P, _P, _I, _P]),
+    "codon_cac_fused_tiles": (_I, [_I, _I]),
+    "codon_cac_fused_finish": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_gate_folded_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "codon_conv2d_gated_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _TP, _P, _P, _P, _P, _P]),
     "codon_conv_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "codon_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _I, _P]),

@@ -254,6 +254,54 @@ int cac_gate_fwd(int B, int H, int W, const float* partials, const float* w1, co
   return check_launch("cac_gate_kernel");
 }
 
+int cac_gate_fwd_n(int B, int ntiles, float inv_hw, const float* partials, const float* w1, const float* b1, const float* w2,
+                   const float* b2, float* ch, float* pools_out, hipStream_t stream) {
+  hipLaunchKernelGGL(cac_gate_kernel, dim3(B), dim3(128), 0, stream, partials, w1, b1, w2, b2, ch, pools_out, ntiles, inv_hw);
+  return check_launch("cac_gate_kernel");
+}
+
+// ---- fused-statistics finish (16-bit path: the conv5x5 + 1x1 epilogue produced the statistics, conv_c8.hip) -----------
+// fold   : (B, ntiles, 128, 2) per-tile {sum, max} -> (B, CODON_CAC_FOLDS, 128, 2): fold f adds tiles [f*per, (f+1)*per) in order
+//          (fixed order: deterministic, batch invariant); cac_gate_kernel then finishes over the CODON_CAC_FOLDS rows
+// combine: pooled (B,2,H,W) = { max(max_c, max_d), (sum_c + sum_d) / 128 } from the two per-stream maps
+__global__ __launch_bounds__(128) void cac_fold_kernel(const float* __restrict__ partials, float* __restrict__ folded,
+                                                       int ntiles, int per) {
+  const int c = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+  const int t0 = f * per, t1 = min(t0 + per, ntiles);
+  float s = 0.f, m = -INFINITY;
+  const float2* p = reinterpret_cast<const float2*>(partials) + (long)b * ntiles * 128 + c;
+  for (int t = t0; t < t1; ++t) {
+    const float2 v = p[(long)t * 128];
+    s += v.x;
+    m = fmaxf(m, v.y);
+  }
+  reinterpret_cast<float2*>(folded)[((long)b * gridDim.x + f) * 128 + c] = make_float2(s, m);
+}
+
+__global__ __launch_bounds__(256) void cac_pool_combine_kernel(const float* __restrict__ pc, const float* __restrict__ pd,
+                                                               float* __restrict__ pooled, long HW, long total) {
+  const long i = blockIdx.x * 256L + threadIdx.x;      // over B * HW pixels
+  if (i >= total) return;
+  const long b = i / HW, q = i - b * HW;
+  const long o = b * 2 * HW + q;
+  pooled[o] = fmaxf(pc[o], pd[o]);
+  pooled[o + HW] = (pc[o + HW] + pd[o + HW]) * (1.f / 128.f);
+}
+
+int cac_fused_finish(int B, int H, int W, int ntiles, const float* partials, const float* pool_c, const float* pool_d,
+                     float* folded, float* pooled, hipStream_t stream) {
+  const long HW = (long)H * W;
+  const int per = (ntiles + CODON_CAC_FOLDS - 1) / CODON_CAC_FOLDS;
+  hipLaunchKernelGGL(cac_fold_kernel, dim3(CODON_CAC_FOLDS, B), dim3(128), 0, stream, partials, folded, ntiles, per);
+  int st = check_launch("cac_fold_kernel");
+  if (st != CODON_OK) return st;
+  const long total = (long)B * HW;
+  CODON_REQUIRE((total + 255) / 256 < (1L << 31), CODON_ERR_UNSUPPORTED, "cac_fused_finish: grid too large");
+  hipLaunchKernelGGL(cac_pool_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pool_c, pool_d,
+                     pooled, HW, total);
+  return check_launch("cac_pool_combine_kernel");
+}
+
 int cac_spatial_fwd(int B, int H, int W, const float* pooled, const float* w, float* sp, hipStream_t stream) {
   const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(pooled) | reinterpret_cast<uintptr_t>(sp)) % 16 == 0);
   const long total = (long)B * H * (v4 ? W / 4 : W);

@@ -42,7 +42,11 @@ int pack_chain1x1_f32x3(const float*, void*, hipStream_t);
 int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const void*, const codon_tensor*,
                             const codon_tensor*, hipStream_t);
 int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*, const void*, const codon_tensor*,
-                         const codon_tensor*, hipStream_t);
+                         const codon_tensor*, float*, float*, int, hipStream_t);
+int cac_fused_tiles(int, int);
+int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
+int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
+                   hipStream_t);
 int conv_chain1x1_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, const codon_tensor*,
                           const codon_tensor*, hipStream_t);
 bool conv_f32x3_supported(const codon_conv_desc*);
@@ -190,13 +194,52 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
                 "conv_chain1x1_fwd: packed weights not 16-byte aligned");
   if (d->dtype == CODON_BF16 || d->dtype == CODON_F16) {
     CODON_REQUIRE(!(d->flags & CODON_CONV_F16X3), CODON_ERR_BAD_ARG, "conv_chain1x1_fwd: F16X3 applies to fp32 tensors");
-    return conv_chain1x1_fwd_16(d, x, w_packed, y, w_chain, out, residual, (hipStream_t)stream);
+    return conv_chain1x1_fwd_16(d, x, w_packed, y, w_chain, out, residual, nullptr, nullptr, 0, (hipStream_t)stream);
   }
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv_chain1x1_fwd: dtype %d", d->dtype);
   if (d->flags & CODON_CONV_F16X3)
     return conv_chain1x1_fwd_f32x3(d, (const float*)x, w_packed, (float*)y, w_chain, out, residual, (hipStream_t)stream);
   return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out,
                                residual, (hipStream_t)stream);
+}
+
+int codon_conv_chain1x1_stats_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
+                                  const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
+                                  float* stats_pool, float* stats_partials, int32_t stats_choff, codon_stream_t stream) {
+  CODON_REQUIRE(d && x && w_packed && w_chain && out && out->data && stats_pool && stats_partials, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_stats_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: bad shape %dx%dx%d",
+                d->batch, d->height, d->width);
+  CODON_REQUIRE(stats_choff == 0 || stats_choff == 64, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_stats_fwd: stats_choff %d (0 = colour stream, 64 = depth stream)", stats_choff);
+  CODON_REQUIRE((d->flags & ~CODON_CONV_RELU) == 0, CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: only the RELU flag applies");
+  CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)w_chain % 16) == 0 && ((uintptr_t)stats_partials % 8) == 0,
+                CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: misaligned buffer");
+  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "conv_chain1x1_stats_fwd: 16-bit tensors only (fp32 takes codon_conv_chain1x1_fwd + codon_cac_stats_fwd)");
+  return conv_chain1x1_fwd_16(d, x, w_packed, y, w_chain, out, residual, stats_pool, stats_partials, stats_choff,
+                              (hipStream_t)stream);
+}
+
+int32_t codon_cac_fused_tiles(int32_t height, int32_t width) {
+  return (height > 0 && width > 0) ? cac_fused_tiles(height, width) : 0;
+}
+
+int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const float* partials, const float* pool_c,
+                           const float* pool_d, float* folded, float* pooled, codon_stream_t stream) {
+  CODON_REQUIRE(partials && pool_c && pool_d && folded && pooled, CODON_ERR_BAD_ARG, "cac_fused_finish: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_fused_finish: bad shape");
+  return cac_fused_finish(batch, height, width, cac_fused_tiles(height, width), partials, pool_c, pool_d, folded, pooled,
+                          (hipStream_t)stream);
+}
+
+int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, const float* folded, const float* w1,
+                              const float* b1, const float* w2, const float* b2, float* ch, float* pools_out,
+                              codon_stream_t stream) {
+  CODON_REQUIRE(folded && w1 && b1 && w2 && b2 && ch, CODON_ERR_BAD_ARG, "cac_gate_folded_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_gate_folded_fwd: bad shape");
+  return cac_gate_fwd_n(batch, CODON_CAC_FOLDS, (float)(1.0 / ((double)height * width)), folded, w1, b1, w2, b2, ch,
+                        pools_out, (hipStream_t)stream);
 }
 
 int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,

@@ -18,6 +18,7 @@
 // The chained 1x1 (FUSE): the rounded 8-channel vectors a lane would store are already the B operand (k = 8h + j in
 // NATURAL channel order, thanks to swap23) of the 128 -> 64 conv that consumes them.
 
+#include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -39,6 +40,10 @@ struct ConvC8Params {
   const uint4* w2;      // [t2][t][g][lane] x 16 B: W1[t2*32 + swap23(lane&31)][t*32 + 16g + 8(lane>>5) + j], j = 0..7
   uint4* y2;
   long y2_img, y2_base;
+  // FUSE only, optional (st_pool != nullptr): CAC statistics of the 64 channels this launch produces, from the epilogue
+  float* st_pool;       // (B,2,H,W): per pixel { max, SUM } over this stream's 64 channels (ChannelPool, CAC_module.py:81)
+  float* st_part;       // (B, tiles, 128, 2): per tile, per channel { sum, max } (first stage of the pools, :43,47)
+  int st_choff;         // 0 = colour stream (Fcat channels 0..63), 64 = depth stream
 };
 
 template <int N, class F, int I = 0>
@@ -59,16 +64,31 @@ enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
 
 // pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is
 // 8 MFMAs on 6 operand fetches
-template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : 2; };
+#ifndef CODON_C8_PSEG3
+#define CODON_C8_PSEG3 2
+#endif
+#ifndef CODON_C8_OCC3
+#define CODON_C8_OCC3 2
+#endif
+#ifndef CODON_C8_NW5128
+#define CODON_C8_NW5128 4
+#endif
+#ifndef CODON_C8_NW564
+#define CODON_C8_NW564 4
+#endif
+template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_C8_PSEG3 : 2; };
+// waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
+template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : 4; };
 
-template <class E, int KS, int CIN, int COUT, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
   typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
   constexpr int PAD = KS / 2;
   constexpr int PSEG = ConvC8Pseg<KS, COUT>::value;
-  constexpr int TW = 32, TH = 4 * PSEG;
+  constexpr int NT = 64 * NW;
+  constexpr int TW = 32, TH = NW * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = 16, NCB = CK / 8;
   constexpr int NCHUNK = CIN / CK;
@@ -76,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
   constexpr int WS = KS * NCB * COUT;      // 16-byte elements per weight stage (one filter row of one chunk)
   constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * KS;
-  constexpr int XE = (XS + 255) / 256, WE = (WS + 255) / 256;
-  constexpr int XSP = XE * 256, WSP = WE * 256;   // padded to whole staging rounds (no store predicates)
+  constexpr int XE = (XS + NT - 1) / NT, WE = (WS + NT - 1) / NT;
+  constexpr int XSP = XE * NT, WSP = WE * NT;     // padded to whole staging rounds (no store predicates)
   static_assert(NCHUNK % 2 == 0, "the stage loop is unrolled over chunk pairs");
   static_assert(2 * XSP * 16 < 65536 && 2 * WSP * 16 < 65536, "LDS immediates are 16 bits per region");
 
@@ -103,11 +123,11 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 16), C8_RSRC_FLAGS);
 
-  // gather plan: element e = tid + 256 k = (plane cb of the chunk, row r, col q) of xs[cb][r][q]; xoff = byte offset of
+  // gather plan: element e = tid + NT k = (plane cb of the chunk, row r, col q) of xs[cb][r][q]; xoff = byte offset of
   // that pixel's vector in plane cb, or out of range (zero padding; padding elements of the last round likewise)
   unsigned xoff[XE];
   {
-    constexpr int DQ = 256 % XQ, DR = (256 / XQ) % XR, DC = (256 / XQ) / XR;
+    constexpr int DQ = NT % XQ, DR = (NT / XQ) % XR, DC = (NT / XQ) / XR;
     int cb = tid / (XR * XQ);
     int rem = tid - cb * (XR * XQ);
     int r = rem / XQ, q = rem - r * XQ;
@@ -123,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
   }
   const lds_w128 xwr = (lds_w128)(xs0 + tid);
   const unsigned wvo = (unsigned)tid * 16u;
-  const unsigned wvo_last = (WS % 256 == 0 || tid + (WE - 1) * 256 < WS) ? wvo : C8_OOB;
+  const unsigned wvo_last = (WS % NT == 0 || tid + (WE - 1) * NT < WS) ? wvo : C8_OOB;
   const lds_w128 ww = (lds_w128)(ws0 + tid);
   const lds_rd xrd = (lds_rd)(xs0 + (half * XR + wave * PSEG) * XQ + l31);
   const lds_rd wrd = (lds_rd)(ws0 + half * COUT + l31);
@@ -140,17 +160,17 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
   }
 #define STORE_X(buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */            \
   {                                                                                     \
-    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xwr[(buf_) * XSP + k * 256] = xv[k - (k0_)]; \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xwr[(buf_) * XSP + k * NT] = xv[k - (k0_)]; \
   }
 #define LOAD_W(stage_)                                                                  \
   {                                                                                     \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
-      wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * 4096u);              \
+      wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16)); \
   }
 #define STORE_W(buf_)                                                                   \
   {                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * 256] = wr[k];  \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * NT] = wr[k];   \
   }
 
   f32x16 acc[PSEG][CT];
@@ -303,6 +323,12 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
           for (int i = 0; i < PSEG; ++i) d[t2][i] = E::mfma(a, *reinterpret_cast<const vec8*>(&pk[i][t][g]), d[t2][i]);
         }
     }
+    float pmx[PSEG], psm[PSEG], csum[32], cmax[32];
+    bool valid[PSEG];
+#pragma unroll
+    for (int i = 0; i < PSEG; ++i) { pmx[i] = -INFINITY; psm[i] = 0.f; valid[i] = vo[i] != C8_OOB; }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { csum[k] = 0.f; cmax[k] = -INFINITY; }
 #pragma unroll
     for (int i = 0; i < PSEG; ++i) {
       u32x4 rv[2][2];
@@ -325,8 +351,73 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const ConvC8Params p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v8[j] += r8[j];
           }
-          c8_st(c8_pack<E>(v8), y2rsrc, vo[i], cplane(t2, g));
+          const u32x4 q = c8_pack<E>(v8);
+          c8_st(q, y2rsrc, vo[i], cplane(t2, g));
+          if (p.st_pool) {       // statistics of the values AS STORED (rounded to 16 bits), like a pass over the tensor
+            float r8[8];
+            c8_unpack<E>(q, r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              pmx[i] = fmaxf(pmx[i], r8[j]);
+              psm[i] += r8[j];
+              csum[t2 * 16 + g * 8 + j] += valid[i] ? r8[j] : 0.f;
+              cmax[t2 * 16 + g * 8 + j] = valid[i] ? fmaxf(cmax[t2 * 16 + g * 8 + j], r8[j]) : cmax[t2 * 16 + g * 8 + j];
+            }
+          }
         }
+    }
+    if (p.st_pool) {
+      // per pixel: this lane holds 32 of the pixel's 64 channels, lane + 32 the other 32
+      const long HWl = (long)H * W;
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i) {
+        const float m2 = fmaxf(pmx[i], __shfl_xor(pmx[i], 32, 64)), s2 = psm[i] + __shfl_xor(psm[i], 32, 64);
+        if (half == 0 && valid[i]) {
+          const long q = (long)(ty0 + wave * PSEG + i) * W + gx;
+          p.st_pool[(long)b * 2 * HWl + q] = m2;
+          p.st_pool[(long)b * 2 * HWl + HWl + q] = s2;
+        }
+      }
+      // per channel: transpose through LDS (free after the last stage's barrier): lane L writes its 32 values as a
+      // row of 36 floats (144-byte pitch: conflict-free ds_write_b128), then lane (c, half) sums column c over the 32
+      // rows of its half; sums first, maxima second, through the same region
+      float* const tr = reinterpret_cast<float*>(lds) + wave * (64 * 36);
+      float* const red = reinterpret_cast<float*>(lds) + NW * (64 * 36);      // [2][NW][64]
+      static_assert((NW * 64 * 36 + 2 * NW * 64) * 4 <= (2 * XSP + 2 * WSP) * 16, "statistics scratch fits the stage buffers");
+      float rs = 0.f, rm = -INFINITY;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const float* src = pass ? cmax : csum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<float4*>(tr + lane * 36 + 4 * k) = make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's own writes have landed
+        __builtin_amdgcn_wave_barrier();
+        float a = pass ? -INFINITY : 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const float v = tr[(half * 32 + r) * 36 + l31];
+          a = pass ? fmaxf(a, v) : a + v;
+        }
+        if (pass) rm = a; else rs = a;
+        __builtin_amdgcn_wave_barrier();
+      }
+      red[(0 * NW + wave) * 64 + lane] = rs;
+      red[(1 * NW + wave) * 64 + lane] = rm;
+      __syncthreads();
+      if (wave == 0) {
+        float s = red[lane], m = red[NW * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {            // fixed order: deterministic
+          s += red[w * 64 + lane];
+          m = fmaxf(m, red[(NW + w) * 64 + lane]);
+        }
+        const int ch = (l31 >> 4) * 32 + ((l31 >> 3) & 1) * 16 + 8 * half + (l31 & 7);   // value index -> channel (swap23 layout)
+        const long tile = (long)ty * p.tiles_x + tx;
+        float2* out = reinterpret_cast<float2*>(p.st_part) +
+                      (((long)b * p.tiles_x * p.tiles_y + tile) * 128 + p.st_choff + ch);
+        *out = make_float2(s, m);
+      }
     }
     return;
   }
@@ -586,6 +677,7 @@ static void c8_fill(ConvC8Params& p, const codon_conv_desc* d, const void* x, co
   p.tiles_x = p.tiles_y = p.nblk = 0;
   p.flags = d->flags;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
+  p.st_pool = nullptr; p.st_part = nullptr; p.st_choff = 0;
 }
 
 template <class E, int CIN, int COUT>
@@ -602,13 +694,14 @@ static int launch_conv1x1_c8(const codon_conv_desc* d, const void* x, const void
 
 template <class E, int KS, int CIN, int COUT, bool FUSE>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
-  constexpr int TH = 4 * ConvC8Pseg<KS, COUT>::value;
+  constexpr int NW = ConvC8Nw<KS, COUT>::value;
+  constexpr int TH = NW * ConvC8Pseg<KS, COUT>::value;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
-  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
   return check_launch("conv_c8_kernel");
 }
 
@@ -645,7 +738,8 @@ int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void
 }
 
 int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,
-                         const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+                         const codon_tensor* out, const codon_tensor* res, float* st_pool, float* st_part, int st_choff,
+                         hipStream_t stream) {
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: 16-bit kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
   CODON_REQUIRE(c8_slice_ok(d->x_ctotal, d->x_coff, 128) && (!y || c8_slice_ok(d->y_ctotal, d->y_coff, 128)) &&
@@ -661,8 +755,15 @@ int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w,
   p.r_base = res ? (res->coff / 8) * HW : 0;
   p.w2 = (const uint4*)w_chain; p.y2 = (uint4*)out->data;
   p.y2_img = (out->ctotal / 8) * HW; p.y2_base = (out->coff / 8) * HW;
+  p.st_pool = st_pool; p.st_part = st_part; p.st_choff = st_choff;
   return d->dtype == CODON_F16 ? launch_conv_c8<C8F16, 5, 128, 128, true>(p, d, stream)
                                : launch_conv_c8<C8Bf16, 5, 128, 128, true>(p, d, stream);
+}
+
+// tiles of the fused-statistics partials: the conv5x5 128->128 kernel's 8 x 32 (NW * PSEG rows) pixel tiles
+int cac_fused_tiles(int H, int W) {
+  constexpr int TH = ConvC8Nw<5, 128>::value * ConvC8Pseg<5, 128>::value;
+  return ((W + 31) / 32) * ((H + TH - 1) / TH);
 }
 
 }  // namespace codon

@@ -238,11 +238,14 @@ class _CODONBase(nn.Module):
         split5 = self._split(5)
         chain_mode = L.PACK_CHAIN1X1_F16X3 if split5 else L.PACK_CHAIN1X1
 
-        def conv5_1x1(xs, name5, name1, mid, ys, residual=None):
+        def conv5_1x1(xs, name5, name1, mid, ys, residual=None, stats=None):
             """ys = conv1x1(relu(conv5x5(xs))) [+ residual]; mid = relu(conv5x5(xs)) is only materialised when the
             backward needs it (one launch: the 1x1 runs from the 5x5's accumulators)."""
             ops.conv_chain1x1(xs, P(name5), P(name1, chain_mode), ys, mid=mid if keep else None, residual=residual,
-                              f16x3=split5)
+                              f16x3=split5, stats=stats)
+
+        # 16-bit tensors: the CAC statistics of a block come out of the two conv5x5 + 1x1 epilogues (no pass over Fcat)
+        fused_stats = ops.is_c8(adt)
 
         # inference, exact fp32: the gate-apply `out*ad_CAC + inputs` (:89-91,117-118) is formed inside the staging of
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
@@ -269,7 +272,11 @@ class _CODONBase(nn.Module):
         if keep:
             save["stem"], save["stem_c"], save["in2"] = t64, t64c, in2
 
-        nt = ops.cac_stats_tiles(H, W)
+        nt = ops.cac_fused_tiles(H, W) if fused_stats else ops.cac_stats_tiles(H, W)
+        fz = dict(dtype=torch.float32, device=dev)
+        if fused_stats:
+            pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
+            folded = torch.empty((B, L.CAC_FOLDS, 128, 2), **fz)
         cur = in2                       # (B,128): [depth | colour] block input
         oc = prev_gate = None
         stage = r2 = stage_c = r2_c = pre2 = None
@@ -288,16 +295,23 @@ class _CODONBase(nn.Module):
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
             gconv(gate, pre, inputs, out, "conv1", Slice(stage, 0, 64), 3)
             gconv(gate, pre, inputs, out, "conv2", Slice(stage, 64, 64), 5)
-            conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre)   # :81,84
+            conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
+                      stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
             gconv(gate, pre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5)
             gconv(gate, pre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3)
-            conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c)   # :82,83
+            conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
+                      stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
-            ops.cac_stats(pre_c, pre, pooled, partials)
-            ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
-                         f32(ac.mlp[3].bias), ch, pools)
+            if fused_stats:
+                ops.cac_fused_finish(B, H, W, partials, pool_c, pool_d, folded, pooled)
+                ops.cac_gate_folded(B, H, W, folded, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                                    f32(ac.mlp[3].bias), ch, pools)
+            else:
+                ops.cac_stats(pre_c, pre, pooled, partials)
+                ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                             f32(ac.mlp[3].bias), ch, pools)
             ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
             if gated:
                 prev_gate = (ch, sp)    # consumed by the next block's convs / conv7

@@ -165,11 +165,14 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
 
 
 def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: Slice, mid: Optional[Slice] = None,
-                  residual: Optional[Slice] = None, f16x3: bool = False):
+                  residual: Optional[Slice] = None, f16x3: bool = False, stats=None):
     """out = conv1x1(relu(conv5x5(x))) [+ residual] in one launch (the 1x1 runs from the 5x5's accumulators);
-    mid, when given, also receives relu(conv5x5(x)) (training saves it)."""
+    mid, when given, also receives relu(conv5x5(x)) (training saves it).  stats = (pool (B,2,H,W), partials
+    (B, cac_fused_tiles, 128, 2), choff in {0, 64}): 16-bit tensors only -- the launch also leaves the CAC statistics of
+    its 64 output channels (csrc/conv_c8.hip; finished by cac_fused_finish + cac_gate_folded)."""
     lib = L.load()
-    dev = _dev(x.buf, w_packed, w_chain, out.buf, mid.buf if mid else None, residual.buf if residual else None)
+    dev = _dev(x.buf, w_packed, w_chain, out.buf, mid.buf if mid else None, residual.buf if residual else None,
+               stats[0] if stats else None, stats[1] if stats else None)
     B, H, W = _bhw(x.buf)
     assert out.c == 64 and _bhw(out.buf) == (B, H, W)
     assert out.buf.dtype == x.buf.dtype and (mid is None or (mid.c == 128 and _bhw(mid.buf) == (B, H, W)))
@@ -183,9 +186,18 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
         ot, rt = out.ct(), (residual.ct() if residual else None)
-        L.check(lib.codon_conv_chain1x1_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed), _ptr(mid.buf if mid else None),
-                                            _ptr(w_chain), C.byref(ot), C.byref(rt) if rt is not None else None,
-                                            _stream(dev)), "conv_chain1x1_fwd")
+        if stats is not None:
+            pool, partials, choff = stats
+            assert pool.dtype == torch.float32 and tuple(pool.shape) == (B, 2, H, W)
+            assert partials.dtype == torch.float32 and tuple(partials.shape) == (B, cac_fused_tiles(H, W), 128, 2)
+            L.check(lib.codon_conv_chain1x1_stats_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed),
+                                                      _ptr(mid.buf if mid else None), _ptr(w_chain), C.byref(ot),
+                                                      C.byref(rt) if rt is not None else None, _ptr(pool), _ptr(partials),
+                                                      choff, _stream(dev)), "conv_chain1x1_stats_fwd")
+        else:
+            L.check(lib.codon_conv_chain1x1_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed), _ptr(mid.buf if mid else None),
+                                                _ptr(w_chain), C.byref(ot), C.byref(rt) if rt is not None else None,
+                                                _stream(dev)), "conv_chain1x1_fwd")
         if prof is not None:
             e1.record(torch.cuda.current_stream(dev))
             prof["events"].append((e0, e1))
@@ -247,6 +259,29 @@ def head(x: Slice, w: torch.Tensor, residual: torch.Tensor, y: torch.Tensor):
 
 def cac_stats_tiles(H: int, W: int) -> int:
     return L.load().codon_cac_stats_tiles(H, W)
+
+
+def cac_fused_tiles(H: int, W: int) -> int:
+    return L.load().codon_cac_fused_tiles(H, W)
+
+
+def cac_fused_finish(B: int, H: int, W: int, partials, pool_c, pool_d, folded, pooled):
+    """Fold the per-tile statistics of the two conv_chain1x1(stats=...) launches and combine their per-stream maps into
+    pooled (B,2,H,W) = {channel max, channel mean}."""
+    lib = L.load()
+    dev = _dev(partials, pool_c, pool_d, folded, pooled)
+    assert tuple(folded.shape) == (B, L.CAC_FOLDS, 128, 2) and tuple(pooled.shape) == (B, 2, H, W)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_fused_finish(B, H, W, _ptr(partials), _ptr(pool_c), _ptr(pool_d), _ptr(folded), _ptr(pooled),
+                                           _stream(dev)), "cac_fused_finish")
+
+
+def cac_gate_folded(B: int, H: int, W: int, folded, w1, b1, w2, b2, ch, pools_out=None):
+    lib = L.load()
+    dev = _dev(folded, w1, b1, w2, b2, ch, pools_out)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_gate_folded_fwd(B, H, W, _ptr(folded), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ch),
+                                              _ptr(pools_out), _stream(dev)), "cac_gate_folded_fwd")
 
 
 def cac_stats(pre_c: Slice, pre: Slice, pooled: torch.Tensor, partials: torch.Tensor):

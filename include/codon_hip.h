@@ -109,6 +109,28 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
                             const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
                             codon_stream_t stream);
 
+/* 16-bit tensors only: codon_conv_chain1x1_fwd that ALSO produces the CAC statistics of its 64 output channels from the
+ * epilogue (the values as stored, i.e. rounded to 16 bits), instead of a separate pass over the tensor
+ * (codon_cac_stats_fwd; F.avg_pool2d / F.max_pool2d / ChannelPool, /root/reference/CODON_X4/CAC_module.py:43,47,81):
+ *   stats_pool     (B,2,H,W) fp32 : per pixel { max, SUM } over THIS stream's 64 channels
+ *   stats_partials (B, codon_cac_fused_tiles(H,W), 128, 2) fp32 : per conv tile, per channel { sum, max } written at
+ *                  channels [stats_choff, stats_choff + 64): 0 = colour stream (Fcat channels 0..63), 64 = depth.
+ * Two launches (one per stream) fill one partials buffer.  Then
+ *   codon_cac_fused_finish   : folds the tiles into CODON_CAC_FOLDS rows in fixed order (`folded`: (B, CODON_CAC_FOLDS, 128, 2)
+ *                              scratch) and combines the two stream maps into pooled (B,2,H,W) = { max, mean over 128 }
+ *   codon_cac_gate_folded_fwd: codon_cac_gate_fwd over the folded rows.
+ * Max pools are exact; sums are added in a different (fixed) order than codon_cac_stats_fwd adds them. */
+#define CODON_CAC_FOLDS 16
+int codon_conv_chain1x1_stats_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
+                                  const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
+                                  float* stats_pool, float* stats_partials, int32_t stats_choff, codon_stream_t stream);
+int32_t codon_cac_fused_tiles(int32_t height, int32_t width);
+int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const float* partials, const float* pool_c,
+                           const float* pool_d, float* folded, float* pooled, codon_stream_t stream);
+int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, const float* folded, const float* w1,
+                              const float* b1, const float* w2, const float* b2, float* ch, float* pools_out,
+                              codon_stream_t stream);
+
 /* A conv whose input is the CAC gate-apply of the producing block, formed while the input tile is staged instead of
  * being written to HBM and read back (inference):   x = pre * (ch * sp) + inputs ,  y = conv(x) [ReLU]
  *   out*ad_CAC + inputs  /  out_c*ad_CAC + inputs_c  feeding conv1, conv2 / conv4, conv5 / conv7

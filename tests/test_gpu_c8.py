@@ -210,3 +210,53 @@ def test_conv_dgrad_and_1x1_against_fp32_kernels(dtype):
         ops.conv2d(Slice(ops.from_nchw(gy, dtype)), ops.packed_weight(w, L.PACK_DGRAD, dtype), Slice(g1), k,
                    relu_mask=Slice(ops.from_nchw(act, dtype)), accumulate=True)
         assert rel_rmse(ops.to_nchw(g1).float().cpu(), g0.cpu()) < _tol(dtype), (k, cin, cout)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 33, 70), (2, 64, 40), (1, 8, 32)])
+def test_fused_statistics_equal_a_pass_over_the_tensor(shape, dtype):
+    """conv_chain1x1(stats=...) + cac_fused_finish + cac_gate_folded (statistics from the conv epilogue) against
+    cac_stats + cac_gate (a pass over the stored tensor): both max pools bit for bit, the sums to fp32 summation order,
+    and the tensors the conv writes identical with and without the statistics."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    nan = lambda c: ops.new_act(B, c, H, W, dtype, dev).fill_(float("nan"))
+    w1, b1, w2, b2 = _rand((8, 128), 7, 0.1).to(dev), _rand((8,), 8, 0.1).to(dev), _rand((64, 8), 9, 0.3).to(dev), _rand((64,), 10, 0.1).to(dev)
+    pre2, ref2 = nan(128), nan(128)
+    nt = ops.cac_fused_tiles(H, W)
+    fz = dict(dtype=torch.float32, device=dev)
+    partials = torch.full((B, nt, 128, 2), float("nan"), **fz)
+    pool = {0: torch.full((B, 2, H, W), float("nan"), **fz), 64: torch.full((B, 2, H, W), float("nan"), **fz)}
+    for choff, seed in ((64, 1), (0, 2)):          # depth stream -> pre2[:, :64], colour stream -> pre2[:, 64:]
+        x = ops.from_nchw(torch.relu(_rand((B, 128, H, W), seed)).to(dev), dtype)
+        w5 = _rand((128, 128, 5, 5), 10 + seed, (2.0 / (25 * 128)) ** 0.5).to(dev)
+        wc = _rand((64, 128, 1, 1), 20 + seed, 0.15).to(dev)
+        wp, wcp = ops.packed_weight(w5, L.PACK_FWD, dtype), ops.packed_weight(wc, L.PACK_CHAIN1X1, dtype)
+        dst = 0 if choff == 64 else 64
+        ops.conv_chain1x1(Slice(x), wp, wcp, Slice(pre2, dst, 64), stats=(pool[choff], partials, choff))
+        ops.conv_chain1x1(Slice(x), wp, wcp, Slice(ref2, dst, 64))
+    assert torch.equal(pre2, ref2) and not torch.isnan(ops.to_nchw(pre2).float()).any()
+    assert not torch.isnan(partials).any() and not torch.isnan(pool[0]).any() and not torch.isnan(pool[64]).any()
+    folded, pooled = torch.empty((B, L.CAC_FOLDS, 128, 2), **fz), torch.empty((B, 2, H, W), **fz)
+    ch, pools = torch.empty((B, 64), **fz), torch.empty((B, 2, 128), **fz)
+    ops.cac_fused_finish(B, H, W, partials, pool[0], pool[64], folded, pooled)
+    ops.cac_gate_folded(B, H, W, folded, w1, b1, w2, b2, ch, pools)
+    # the same quantities from a pass over the stored tensor
+    nt0 = ops.cac_stats_tiles(H, W)
+    pooled0, partials0 = torch.empty((B, 2, H, W), **fz), torch.empty((B, nt0, 128, 2), **fz)
+    ch0, pools0 = torch.empty((B, 64), **fz), torch.empty((B, 2, 128), **fz)
+    ops.cac_stats(Slice(pre2, 64, 64), Slice(pre2, 0, 64), pooled0, partials0)
+    ops.cac_gate(B, H, W, partials0, w1, b1, w2, b2, ch0, pools0)
+    assert torch.equal(pooled[:, 0], pooled0[:, 0])                      # channel max
+    assert torch.equal(pools[:, 1], pools0[:, 1])                        # global max pool
+    scale = float(pooled0[:, 1].abs().max()) + 1e-30
+    assert float((pooled[:, 1] - pooled0[:, 1]).abs().max()) <= 2e-6 * scale
+    assert float((pools[:, 0] - pools0[:, 0]).abs().max()) <= 2e-6 * (float(pools0[:, 0].abs().max()) + 1e-30)
+    assert float((ch - ch0).abs().max()) <= 1e-6
+    # torch restatement of the pools on the stored values
+    F2 = ops.to_nchw(pre2).float()
+    Fcat = torch.cat((F2[:, 64:], F2[:, :64]), 1)
+    assert torch.equal(pools[:, 1], Fcat.amax((2, 3)))
+    assert rel_rmse(pools[:, 0].cpu(), Fcat.double().mean((2, 3)).float().cpu()) < 1e-6

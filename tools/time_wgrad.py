@@ -9,8 +9,11 @@ cases = [(5, 128, 128), (5, 64, 64), (3, 64, 64), (1, 128, 64)]
 if len(sys.argv) > 2:
     cases = [cases[int(sys.argv[2])]]
 for (k, ci, co) in cases:
-    x = torch.randn((B, ci, H, W), device=dev).to(dt)
-    g = torch.randn((B, co, H, W), device=dev).to(dt)
+    x = torch.randn((B, ci, H, W), device=dev)
+    if os.environ.get("DATA") == "relu":
+        x = torch.relu(x)
+    x = ops.from_nchw(x, dt)
+    g = ops.from_nchw(torch.randn((B, co, H, W), device=dev), dt)
     dw = torch.empty((co, ci, k, k), device=dev)
     ops.conv2d_wgrad(Slice(x), Slice(g), dw, k)
     torch.cuda.synchronize()
