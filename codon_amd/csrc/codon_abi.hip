@@ -43,6 +43,8 @@ int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, f
                             const codon_tensor*, hipStream_t);
 int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*, const void*, const codon_tensor*,
                          const codon_tensor*, float*, float*, int, hipStream_t);
+int conv2d_gated_fwd_16(const codon_conv_desc*, const void*, const codon_tensor*, const float*, const float*, const void*,
+                        void*, hipStream_t);
 int cac_fused_tiles(int, int);
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -257,7 +259,9 @@ int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codo
                 "conv2d_gated_fwd: output slice outside its buffer");
   CODON_REQUIRE((d->flags & ~CODON_CONV_RELU) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: only the RELU flag applies");
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: packed weights not 16-byte aligned");
-  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: dtype %d (fp32 only)", d->dtype);
+  if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
+    return conv2d_gated_fwd_16(d, pre, inputs, ch, sp, w_packed, y, (hipStream_t)stream);
+  CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: dtype %d", d->dtype);
   return conv2d_gated_fwd_f32(d, (const float*)pre, inputs, ch, sp, (const float*)w_packed, (float*)y, (hipStream_t)stream);
 }
 

@@ -40,6 +40,11 @@ struct ConvC8Params {
   const uint4* w2;      // [t2][t][g][lane] x 16 B: W1[t2*32 + swap23(lane&31)][t*32 + 16g + 8(lane>>5) + j], j = 0..7
   uint4* y2;
   long y2_img, y2_base;
+  // GATE only: the staged input is pre * (ch * sp) + inputs (CAC gate-apply of the producing block), x = pre
+  const uint4* gin;     // `inputs` buffer
+  long g_img, g_base;
+  const float* gch;     // (B,64) channel gate: channel c of the slice uses gch[c & 63]
+  const float* gsp;     // (B,1,H,W) spatial gate
   // FUSE only, optional (st_pool != nullptr): CAC statistics of the 64 channels this launch produces, from the epilogue
   float* st_pool;       // (B,2,H,W): per pixel { max, SUM } over this stream's 64 channels (ChannelPool, CAC_module.py:81)
   float* st_part;       // (B, tiles, 128, 2): per tile, per channel { sum, max } (first stage of the pools, :43,47)
@@ -80,7 +85,7 @@ template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (CO
 // waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
 template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : 4; };
 
-template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4>
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
@@ -126,6 +131,8 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   // gather plan: element e = tid + NT k = (plane cb of the chunk, row r, col q) of xs[cb][r][q]; xoff = byte offset of
   // that pixel's vector in plane cb, or out of range (zero padding; padding elements of the last round likewise)
   unsigned xoff[XE];
+  int xcb[GATE ? XE : 1];        // GATE: plane (0 / 1) of the element inside its chunk, and its pixel's spatial gate
+  float xsp[GATE ? XE : 1];
   {
     constexpr int DQ = NT % XQ, DR = (NT / XQ) % XR, DC = (NT / XQ) / XR;
     int cb = tid / (XR * XQ);
@@ -136,11 +143,22 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
       const bool ok = cb < NCB && gy >= 0 && gy < H && gx >= 0 && gx < W;
       xoff[k] = ok ? (unsigned)cb * HW16 + 16u * (unsigned)(gy * W + gx) : C8_OOB;
+      if constexpr (GATE) {
+        xcb[k] = cb & 1;
+        const float g_ = p.gsp[(long)b * H * W + (ok ? gy * W + gx : 0)];
+        xsp[k] = ok ? g_ : 0.f;
+      }
       q += DQ; r += DR; cb += DC;
       if (q >= XQ) { q -= XQ; r += 1; }
       if (r >= XR) { r -= XR; cb += 1; }
     }
   }
+  __shared__ float chs[GATE ? 64 : 1];
+  if constexpr (GATE) {
+    if (tid < 64) chs[tid] = p.gch[b * 64 + tid];
+  }
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(GATE ? p.gin + (long)b * p.g_img + p.g_base : p.x), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
   const lds_w128 xwr = (lds_w128)(xs0 + tid);
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (WS % NT == 0 || tid + (WE - 1) * NT < WS) ? wvo : C8_OOB;
@@ -151,16 +169,35 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   // the next chunk's halo tile is requested in two halves, during the last two filter rows of the current chunk
   constexpr int XE1 = XE / 2, XEH = XE - XE1;
   u32x4 xv[XEH];
+  u32x4 xg[GATE ? XEH : 1];
   u32x4 wr[WE];
 
 #define LOAD_X(chunk_, k0_, k1_)                                                        \
   {                                                                                     \
     const unsigned so_ = (unsigned)(chunk_) * (unsigned)NCB * HW16;                     \
-    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_); \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
+      xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_);                                       \
+      if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, xoff[k], so_);                   \
+    }                                                                                   \
   }
-#define STORE_X(buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */            \
+  // GATE: the staged vector is pre * (ch * sp) + inputs, formed in fp32 and rounded once -- the arithmetic of
+  // cac_apply_c8_kernel followed by a plain load, bit for bit (out-of-image elements: 0 * g + 0 = 0)
+#define STORE_X(chunk_, buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */    \
   {                                                                                     \
-    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) xwr[(buf_) * XSP + k * NT] = xv[k - (k0_)]; \
+    _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
+      if constexpr (GATE) {                                                             \
+        const float* cg_ = chs + ((((chunk_) * NCB + xcb[k]) * 8) & 63);                \
+        const float4 c0_ = *reinterpret_cast<const float4*>(cg_), c1_ = *reinterpret_cast<const float4*>(cg_ + 4); \
+        const float cg8_[8] = {c0_.x, c0_.y, c0_.z, c0_.w, c1_.x, c1_.y, c1_.z, c1_.w};   \
+        float v_[8], q_[8];                                                             \
+        c8_unpack<E>(xv[k - (k0_)], v_);                                                \
+        c8_unpack<E>(xg[k - (k0_)], q_);                                                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) v_[j] = fmaf(v_[j], cg8_[j] * xsp[k], q_[j]); \
+        xwr[(buf_) * XSP + k * NT] = c8_pack<E>(v_);                                    \
+      } else {                                                                          \
+        xwr[(buf_) * XSP + k * NT] = xv[k - (k0_)];                                     \
+      }                                                                                 \
+    }                                                                                   \
   }
 #define LOAD_W(stage_)                                                                  \
   {                                                                                     \
@@ -181,13 +218,14 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
+  if constexpr (GATE) __syncthreads();        // chs
   if constexpr (XE1 > 0) {
     LOAD_X(0, 0, XE1);
-    STORE_X(0, 0, XE1);
+    STORE_X(0, 0, 0, XE1);
   }
   LOAD_X(0, XE1, XE);
   LOAD_W(0);
-  STORE_X(0, XE1, XE);
+  STORE_X(0, 0, XE1, XE);
   STORE_W(0);
   __syncthreads();
 
@@ -246,11 +284,11 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
 #undef FETCH_B
 
       if constexpr (XE1 > 0 && dy == KS - 2) {
-        if (!(par == 1 && c2 + 2 >= NCHUNK)) STORE_X(par ^ 1, 0, XE1);
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) STORE_X(chunk + 1, par ^ 1, 0, XE1);
       }
       if (has_next) {
         STORE_W(sbuf ^ 1);
-        if constexpr (dy == KS - 1) STORE_X(par ^ 1, XE1, XE);
+        if constexpr (dy == KS - 1) STORE_X(chunk + 1, par ^ 1, XE1, XE);
       }
       __syncthreads();
     });
@@ -678,6 +716,7 @@ static void c8_fill(ConvC8Params& p, const codon_conv_desc* d, const void* x, co
   p.flags = d->flags;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.st_pool = nullptr; p.st_part = nullptr; p.st_choff = 0;
+  p.gin = nullptr; p.g_img = p.g_base = 0; p.gch = nullptr; p.gsp = nullptr;
 }
 
 template <class E, int CIN, int COUT>
@@ -692,7 +731,7 @@ static int launch_conv1x1_c8(const codon_conv_desc* d, const void* x, const void
   return check_launch("conv1x1_c8_kernel");
 }
 
-template <class E, int KS, int CIN, int COUT, bool FUSE>
+template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
   constexpr int TH = NW * ConvC8Pseg<KS, COUT>::value;
@@ -701,7 +740,7 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
-  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
+  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
   return check_launch("conv_c8_kernel");
 }
 
@@ -758,6 +797,34 @@ int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w,
   p.st_pool = st_pool; p.st_part = st_part; p.st_choff = st_choff;
   return d->dtype == CODON_F16 ? launch_conv_c8<C8F16, 5, 128, 128, true>(p, d, stream)
                                : launch_conv_c8<C8Bf16, 5, 128, 128, true>(p, d, stream);
+}
+
+// y = conv(pre * (ch * sp) + inputs) [ReLU]: the gate-apply formed while the halo tile is staged (inference)
+template <class E>
+static int conv2d_gated_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
+  const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
+  switch (key) {
+    case 5064064: return launch_conv_c8<E, 5, 64, 64, false, true>(p, d, stream);
+    case 3064064: return launch_conv_c8<E, 3, 64, 64, false, true>(p, d, stream);
+    case 3128064: return launch_conv_c8<E, 3, 128, 64, false, true>(p, d, stream);
+    default:
+      set_error("conv2d_gated_fwd: no 16-bit kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
+      return CODON_ERR_UNSUPPORTED;
+  }
+}
+
+int conv2d_gated_fwd_16(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                        const float* sp, const void* w, void* y, hipStream_t stream) {
+  CODON_REQUIRE(c8_desc_ok(d, false) && c8_slice_ok(inputs->ctotal, inputs->coff, d->cin), CODON_ERR_BAD_ARG,
+                "conv2d_gated_fwd: 16-bit tensors are channel-blocked: ctotal / coff / channels multiples of 8");
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_gated_fwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  ConvC8Params p;
+  c8_fill(p, d, pre, w, y, nullptr);
+  p.gin = (const uint4*)inputs->data; p.g_img = (inputs->ctotal / 8) * HW; p.g_base = (inputs->coff / 8) * HW;
+  p.gch = ch; p.gsp = sp;
+  return d->dtype == CODON_F16 ? conv2d_gated_c8<C8F16>(p, d, stream) : conv2d_gated_c8<C8Bf16>(p, d, stream);
 }
 
 // tiles of the fused-statistics partials: the conv5x5 128->128 kernel's 8 x 32 (NW * PSEG rows) pixel tiles

@@ -23,6 +23,12 @@ from . import ops
 from .ops import Slice
 
 
+import os as _os
+
+# inference, 16-bit tensors: form the gate-apply in the consuming convs' staging (True) or as a pass (False); A/B switch
+GATED_16BIT = _os.environ.get("CODON_GATED16", "1") != "0"
+
+
 class Conv2dParams(nn.Module):
     """Parameter holder with nn.Conv2d's attribute names (weight is OIHW, no bias)."""
 
@@ -249,7 +255,7 @@ class _CODONBase(nn.Module):
 
         # inference, exact fp32: the gate-apply `out*ad_CAC + inputs` (:89-91,117-118) is formed inside the staging of
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
-        gated = (not keep) and adt == torch.float32 and not split5
+        gated = (not keep) and not split5 and (adt == torch.float32 or GATED_16BIT)
 
         def gconv(gate, pre_s, in_s, plain_s, name, ys, k):
             """relu(conv_k(gate-applied input)): `gate` = (ch, sp) of the producing block or None (plain input)."""

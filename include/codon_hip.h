@@ -138,7 +138,7 @@ int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, cons
  * d->x_* describe `pre` (channels of the (B,128,H,W) [pre | pre_c] buffer); `inputs` = the same channels of
  * [inputs | inputs_c]; ch: (B,64) fp32 channel gate (channel c of the 128 uses ch[c & 63]); sp: (B,1,H,W) fp32 spatial
  * gate.  flags: CODON_CONV_RELU only.  Same arithmetic as codon_cac_apply_fwd followed by codon_conv2d_fwd, bit for
- * bit.  fp32, (k, cin, cout) in {(5,64,64), (3,64,64), (3,128,64)}. */
+ * bit.  Any dtype, (k, cin, cout) in {(5,64,64), (3,64,64), (3,128,64)}. */
 int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
                            const float* sp, const void* w_packed, void* y, codon_stream_t stream);
 

@@ -260,3 +260,28 @@ def test_fused_statistics_equal_a_pass_over_the_tensor(shape, dtype):
     Fcat = torch.cat((F2[:, 64:], F2[:, :64]), 1)
     assert torch.equal(pools[:, 1], Fcat.amax((2, 3)))
     assert rel_rmse(pools[:, 0].cpu(), Fcat.double().mean((2, 3)).float().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("kcc", [(5, 64, 64), (3, 64, 64), (3, 128, 64)])
+def test_gated_conv_equals_apply_then_conv(kcc, dtype):
+    """codon_conv2d_gated_fwd on blocked tensors == cac_apply followed by conv2d, bit for bit (the gate-apply of
+    CODON_x4.py:89-91,117-118 formed while the consumer stages its input)."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    k, cin, cout = kcc
+    for (B, H, W) in [(2, 19, 45), (1, 1, 1), (1, 33, 70)]:
+        pre2 = ops.from_nchw(_rand((B, 128, H, W), 1).to(dev), dtype)
+        in2 = ops.from_nchw(torch.relu(_rand((B, 128, H, W), 2)).to(dev), dtype)
+        ch, sp = torch.rand((B, 64), device=dev), torch.rand((B, 1, H, W), device=dev)
+        w = _rand((cout, cin, k, k), 3, (2.0 / (k * k * cout)) ** 0.5).to(dev)
+        wp = ops.packed_weight(w, dtype=dtype)
+        oc = ops.new_act(B, 128, H, W, dtype, dev)
+        ops.cac_apply(Slice(pre2, 0, 64), Slice(pre2, 64, 64), ch, sp, Slice(in2, 0, 64), Slice(in2, 64, 64),
+                      Slice(oc, 0, 64), Slice(oc, 64, 64))
+        off = 0 if cin == 128 else 64
+        y0, y1 = ops.new_act(B, cout, H, W, dtype, dev), ops.new_act(B, cout, H, W, dtype, dev).fill_(float("nan"))
+        ops.conv2d(Slice(oc, off, cin), wp, Slice(y0), k, relu=True)
+        ops.conv2d_gated(Slice(pre2, off, cin), Slice(in2, off, cin), ch, sp, wp, Slice(y1), k, relu=True)
+        assert torch.equal(y0, y1)
