@@ -86,9 +86,19 @@ _lock = threading.Lock()
 _lib = None
 
 
+_warned_override = False
+
+
 def lib_path() -> str:
-    """In-tree library; CODON_AMD_LIB names another build of it (kernel A/B timing, tools/ab_build.sh)."""
-    return os.environ.get("CODON_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """In-tree library; CODON_AMD_LIB names another build of it (kernel A/B timing, tools/ab_build.sh) -- said once
+    on stderr, because it redirects the product library for every consumer in the process."""
+    global _warned_override
+    override = os.environ.get("CODON_AMD_LIB")
+    if override and not _warned_override:
+        _warned_override = True
+        import sys
+        print(f"codon_amd: CODON_AMD_LIB overrides the in-tree {LIB_NAME}: loading {override}", file=sys.stderr)
+    return override or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 def load():
@@ -126,14 +136,17 @@ def build_info() -> dict:
     csrc = os.path.join(here, "csrc")
     names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
     files = [os.path.join(csrc, n) for n in names] + [os.path.join(os.path.dirname(here), "include", "codon_hip.h")]
-    h = hashlib.sha256()
-    for f in files:
-        with open(f, "rb") as fh:
-            h.update(fh.read())
     path = lib_path()
-    return {"path": path, "source_hash_built": load().codon_build_source_hash().decode(),
-            "source_hash_now": h.hexdigest()[:32], "so_mtime": os.path.getmtime(path),
-            "newest_source_mtime": max(os.path.getmtime(f) for f in files)}
+    info = {"path": path, "source_hash_built": load().codon_build_source_hash().decode(),
+            "source_hash_now": None, "so_mtime": os.path.getmtime(path), "newest_source_mtime": None}
+    if names and all(os.path.exists(f) for f in files):   # an installed package may ship the .so without its sources
+        h = hashlib.sha256()
+        for f in files:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        info["source_hash_now"] = h.hexdigest()[:32]
+        info["newest_source_mtime"] = max(os.path.getmtime(f) for f in files)
+    return info
 
 
 def check(status: int, what: str):

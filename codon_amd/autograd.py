@@ -76,6 +76,18 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     def Pd(name):
         return model._packed(name, L.PACK_DGRAD)
 
+    scratch = {}
+
+    def restage(saved, xs: Slice, first, second):
+        """`stage` = cat(relu(conv_a(x)), relu(conv_b(x))): the saved tensor, or -- model.set_recompute() -- the two
+        sibling convs run again from the saved block input (same kernels, same packed weights: bit-identical)."""
+        if saved is not None:
+            return saved
+        buf = scratch.setdefault("stage", new(128))
+        ops.conv2d(xs, model._packed(first[0]), Slice(buf, 0, 64), first[1], relu=True)
+        ops.conv2d(xs, model._packed(second[0]), Slice(buf, 64, 64), second[1], relu=True)
+        return buf
+
     def wgrad(name, xs: Slice, gs: Slice, k: int):
         key = name + ".weight"
         if key in G:
@@ -100,7 +112,8 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     g_r2, g_stage = new(128), new(128)
     for i in (2, 1, 0):
         T = S[f"trunk{i}"]
-        xin, stage, r2 = T["x"], T["stage"], T["r2"]
+        xin, r2 = T["x"], T["r2"]
+        stage = restage(T["stage"], Slice(xin), ("conv8", 5), ("conv9", 3))
         # f_{i+1} = confuse_fuse(r2) + fuse
         if g_fuse is None:
             g_fuse = g_f.clone()
@@ -130,7 +143,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     g_pre2 = new(128)
     for i in (4, 3, 2, 1, 0):
         Bk = S[f"blk{i}"]
-        xin, stage, r2, stage_c, r2_c, pre2 = Bk["x"], Bk["stage"], Bk["r2"], Bk["stage_c"], Bk["r2_c"], Bk["pre2"]
+        xin, r2, r2_c, pre2 = Bk["x"], Bk["r2"], Bk["r2_c"], Bk["pre2"]
         ac, asp = getattr(model, f"attention_c{i}"), getattr(model, f"attention_s{i}")
         if debug is not None:
             debug[f"g_oc{i}"] = g_oc.clone()
@@ -149,6 +162,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         else:
             g_x, acc0 = g_in2, True
         # depth stream: pre = confuse(r2); r2 = relu(conv3(stage)); stage = [relu(conv1(x)) | relu(conv2(x))]
+        stage = restage(Bk["stage"], Slice(xin, 0, 64), ("conv1", 3), ("conv2", 5))
         wgrad("confuse", Slice(r2), Slice(g_pre2, 0, 64), 1)
         ops.conv2d(Slice(g_pre2, 0, 64), Pd("confuse"), Slice(g_r2), 1, relu_mask=Slice(r2))
         wgrad("conv3", Slice(stage), Slice(g_r2), 5)
@@ -158,6 +172,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_stage, 0, 64), Pd("conv1"), Slice(g_x, 0, 64), 3, accumulate=acc0)
         ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True)
         # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
+        stage_c = restage(Bk["stage_c"], Slice(xin, 64, 64), ("conv4", 5), ("conv5", 3))
         wgrad("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), 1)
         ops.conv2d(Slice(g_pre2, 64, 64), Pd("confuse_c"), Slice(g_r2), 1, relu_mask=Slice(r2_c))
         wgrad("conv6", Slice(stage_c), Slice(g_r2), 5)

@@ -40,6 +40,9 @@ class GradSync:
             n = p.numel()
             v = self.flat[off:off + n].view_as(p)
             if p.grad is None:
+                # dropped by optimizer.zero_grad(set_to_none=True): the slice still holds the previous step's averaged
+                # gradient -- clear it, or a parameter that receives no gradient this step would inherit the old one
+                v.zero_()
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)                    # a gradient produced outside the buffer: adopt it, then alias
@@ -56,7 +59,11 @@ class GradSync:
             return
         with torch.no_grad():
             for p in list(self.params) + self._unused:
-                dist.broadcast(p, src=src, group=self.group)   # on the parameter itself: bumps Tensor._version
+                dist.broadcast(p, src=src, group=self.group)
+                # a collective writes the tensor without bumping Tensor._version (measured: gloo, torch 2.10); bump it
+                # so that everything keyed on (data_ptr, _version) -- the packed-weight cache, GraphedCODON.stale() --
+                # sees the new values
+                torch.autograd.graph.increment_version(p)
         if hasattr(self._model, "invalidate_packed"):
             self._model.invalidate_packed()        # packed MFMA weight images of the old values must not survive
 

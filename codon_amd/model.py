@@ -27,6 +27,9 @@ import os as _os
 
 # inference, 16-bit tensors: form the gate-apply in the consuming convs' staging (True) or as a pass (False); A/B switch
 GATED_16BIT = _os.environ.get("CODON_GATED16", "1") != "0"
+# debug: re-pack on every cache hit and compare, so a write through `.data` after the first forward (the reference's own
+# init idiom is m.weight.data.normal_(), CODON_x4.py:50-53) raises instead of silently using stale packed weights
+VERIFY_PACKED = _os.environ.get("CODON_VERIFY_PACKED", "0") != "0"
 
 
 class Conv2dParams(nn.Module):
@@ -124,6 +127,14 @@ class _CODONBase(nn.Module):
         self._pack_cache: Dict[str, tuple] = {}
         self.compute_dtype: Optional[torch.dtype] = None
         self.conv_precision: str = "exact"
+        self.recompute: bool = False
+
+    def set_recompute(self, on: bool = True):
+        """Training memory switch: do not keep the 13 `stage` tensors (cat(relu(conv1), relu(conv2)) and siblings,
+        CODON_x4.py:79,80,125 -- 128 channels each); the backward re-runs the two sibling convs from the saved block
+        input instead.  fp32 at batch 32, 480x640: 232 GB -> 167 GB of the 288 GB, for 26 extra small convs per step."""
+        self.recompute = bool(on)
+        return self
 
     def set_conv_precision(self, mode: str):
         """fp32 path only.  "exact" (default): v_mfma_f32_32x32x2_f32, bitwise fp32 fmaf chains.
@@ -160,6 +171,10 @@ class _CODONBase(nn.Module):
         tag = (w.data_ptr(), w._version, w.device, w.dtype)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == tag:
+            if VERIFY_PACKED and not torch.equal(hit[1], ops.packed_weight(w.detach(), mode, adt)):
+                raise RuntimeError(f"codon_amd: the packed image of {name}.weight is stale -- the weight was written "
+                                   "through `.data` (or another path that does not bump Tensor._version) after it was "
+                                   "packed; call model.invalidate_packed() after such writes")
             return hit[1]
         packed = ops.packed_weight(w.detach(), mode, adt)
         self._pack_cache[key] = (tag, packed)
@@ -287,9 +302,12 @@ class _CODONBase(nn.Module):
         oc = prev_gate = None
         stage = r2 = stage_c = r2_c = pre2 = None
         for i in range(5):
+            drop_stage = keep and getattr(self, "recompute", False)
             if keep or stage is None:
-                stage, r2, pre2 = new(128), new(128), new(128)
-                stage_c, r2_c = (new(128), new(128)) if keep else (stage, r2)
+                stage = stage if (drop_stage and stage is not None) else new(128)
+                r2, pre2 = new(128), new(128)
+                stage_c = (stage_c if (drop_stage and stage_c is not None) else new(128)) if keep else stage
+                r2_c = new(128) if keep else r2
                 pooled = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
                 partials = torch.empty((B, nt, 128, 2), dtype=torch.float32, device=dev)
                 sp = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
@@ -326,7 +344,8 @@ class _CODONBase(nn.Module):
                     oc = new(128)       # [out | out_c]: also conv7's cat(out, out_c) input  :119
                 ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
             if keep:
-                save[f"blk{i}"] = dict(x=cur, stage=stage, r2=r2, stage_c=stage_c, r2_c=r2_c, pre2=pre2,
+                save[f"blk{i}"] = dict(x=cur, stage=None if drop_stage else stage, r2=r2,
+                                       stage_c=None if drop_stage else stage_c, r2_c=r2_c, pre2=pre2,
                                        pooled=pooled, pools=pools, ch=ch, sp=sp)
             if not gated:
                 cur = oc
@@ -344,12 +363,13 @@ class _CODONBase(nn.Module):
             fA = new(64)
         for i in range(3):
             if keep:
-                stage, r2, fA = new(128), new(128), new(64)
+                stage = stage if (drop_stage and stage is not None) else new(128)
+                r2, fA = new(128), new(64)
             conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
             conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
             conv5_1x1(Slice(stage), "conv10", "confuse_fuse", Slice(r2), Slice(fA), residual=Slice(fuse))  # :126-128
             if keep:
-                save[f"trunk{i}"] = dict(x=f, stage=stage, r2=r2)
+                save[f"trunk{i}"] = dict(x=f, stage=None if drop_stage else stage, r2=r2)
             f = fA
         # tail                                                                       :129-132
         t = new(64) if keep else t64

@@ -48,7 +48,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 # bench.py sets PROFILE = {"key": (ksize, cin, cout), "events": []} to bracket every launch of one conv
-# variant with HIP events recorded on the launch stream (the live roofline measurement).
+# variant with HIP events recorded on the launch stream (the live roofline measurement); "wgrad_key" /
+# "wgrad_events" do the same for one weight-gradient shape (the wgrad launch + its fixed-order reduce).
 PROFILE = None
 
 
@@ -232,9 +233,16 @@ def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: 
     if nbytes == 0:
         raise RuntimeError(f"codon_amd: no wgrad kernel for k={ksize} cin={x.c} cout={gy.c}")
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    prof = PROFILE if (PROFILE is not None and PROFILE.get("wgrad_key") == (ksize, x.c, gy.c)) else None
     with torch.cuda.device(dev):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         L.check(lib.codon_conv2d_wgrad(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(dw), _ptr(ws), nbytes,
                                        1 if accumulate else 0, _stream(dev)), "conv2d_wgrad")
+        if prof is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            prof["wgrad_events"].append((e0, e1))
 
 
 def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):

@@ -157,10 +157,17 @@ def cac_spatial(Fcat, ws):
 
 
 def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
-            taps: Optional[dict] = None) -> torch.Tensor:
+            taps: Optional[dict] = None, masks=None) -> torch.Tensor:
     """CODONNet.forward(x, y), CODON_x4.py:66-132.  `taps`, if given, receives
-    per-stage intermediates under stable names."""
-    r = F.relu
+    per-stage intermediates under stable names.  `masks` (test infrastructure): an iterable of
+    boolean tensors, one per ReLU in call order -- each ReLU then is z * mask instead of
+    max(z, 0), so two implementations whose pre-activations differ by summation noise around
+    zero can be compared on IDENTICAL masks (the gradient is discontinuous there)."""
+    if masks is None:
+        r = F.relu
+    else:
+        it = iter(masks)
+        r = lambda z: z * next(it).to(z.dtype)
     w = lambda k: sd[k + ".weight"]
     residual = x                                                  # :67
     inputs = r(_conv(r(_conv(x, w("input"))), w("conv_input")))          # :68-69
@@ -286,10 +293,15 @@ def loss_l1(pred, target):
     return (pred - target).abs().mean()
 
 
-def grads(sd, x, y, target):
-    """Autograd gradients of loss_l1 w.r.t. every used parameter (44 tensors)."""
+def grads(sd, x, y, target, masks=None, upstream=None):
+    """Autograd gradients of loss_l1 w.r.t. every used parameter (44 tensors).  `masks`: see forward();
+    `upstream`: use this dL/d(out) instead of the L1 loss's own (its sign is discontinuous too)."""
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    out = forward(p, x, y)
+    out = forward(p, x, y, masks=masks)
+    if upstream is not None:
+        used = [k for k in p if not (k.startswith("attention_c5") or k.startswith("attention_s5"))]
+        gs = torch.autograd.grad(out, [p[k] for k in used], grad_outputs=upstream)
+        return float(loss_l1(out.detach(), target)), {k: g for k, g in zip(used, gs)}, out.detach()
     loss = loss_l1(out, target)
     used = [k for k in p if not (k.startswith("attention_c5") or k.startswith("attention_s5"))]
     gs = torch.autograd.grad(loss, [p[k] for k in used])

@@ -48,6 +48,59 @@ def test_bench_self_launches_two_ranks():
     assert abs(d["value"] - 2 * 2 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_four_ranks_strong_scaling_and_diagnostics():
+    """4 self-launched ranks sharing the one GPU (gloo rehearsal of the 8-GPU run), --scaling strong: 8 images IN TOTAL,
+    2 per rank; rank 0's line carries what a mis-bound multi-GPU run would need to be diagnosed from the record alone."""
+    d = _run(["--gpus", "4", "--backend", "gloo", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--batch", "8",
+              "--height", "64", "--width", "96"])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["rccl_ranks"] == 4
+    assert d["config"]["batch_per_gpu"] == 2 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3] and all(r["device"] and r["hostname"] for r in d["ranks"])
+    assert d["versions"]["hip"] and d["versions"]["torch"]
+    fb = d["fwd_bwd"]
+    assert fb["scaling"] == "strong" and fb["global_batch"] == 8 and fb["rccl_ranks"] == 4
+    assert fb["allreduce_us"] > 0 and fb["allreduce_bytes"] == 1865506 * 4
+    assert fb["step_events"]["n"] == fb["steps"] and fb["step_events"]["min_ms"] <= fb["step_events"]["median_ms"]
+    assert d["step_events"]["n"] == d["steps"]
+    assert fb["roofline"]["launches_timed"] == 13 * fb["steps"] and 0 < fb["roofline"]["frac"] < 1.05
+
+
+@pytest.mark.gpu
+def test_bench_retries_a_taken_rendezvous_port_and_times_out(capfd):
+    """self_launch: a port that is taken between bind-and-close and the children's bind is retried on another one; a
+    wall-clock limit terminates the children (exact PIDs) and returns non-zero."""
+    import socket
+    sys.path.insert(0, ROOT)
+    import bench
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0))
+    busy.listen(1)
+    real, calls = bench._free_port, []
+
+    def fake():
+        calls.append(1)
+        return busy.getsockname()[1] if len(calls) == 1 else real()
+
+    bench._free_port = fake
+    try:
+        args = ["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--batch", "1", "--height", "32",
+                "--width", "32", "--no-fwd-bwd"]
+        env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+        rc = bench.self_launch(2, args)
+        out = capfd.readouterr()
+        assert rc == 0 and len(calls) >= 2, out.err[-3000:]
+        assert "retrying on another port" in out.err and out.out.count('"metric"') == 1
+        rc = bench.self_launch(2, args, timeout_s=0.5)
+        out = capfd.readouterr()
+        assert rc == 124 and "terminated" in out.err
+        os.environ.update(env)
+    finally:
+        bench._free_port = real
+        busy.close()
+
+
 def test_bench_refuses_without_gpu_and_propagates_child_failure():
     """CPU-checkable half of the launcher: no GPU -> every child exits non-zero -> the parent does too (no JSON line)."""
     import torch

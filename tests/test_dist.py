@@ -36,7 +36,11 @@ def _worker(rank, world, port, q):
     m = CODONNet()
     gs = GradSync(m)
     assert gs.numel == 1865506 and len(gs.params) == 44
+    v0 = [p._version for p in m.parameters()]
     gs.broadcast_parameters(src=0)
+    # the collective itself does not bump Tensor._version; broadcast_parameters must (GraphedCODON.stale()
+    # and the packed-weight cache key on it), for the unused attention_*5 tensors as well
+    assert all(p._version > v for p, v in zip(m.parameters(), v0))
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     # global batch of 4 images, sharded by image
     B, H, W = 4, 12, 10
@@ -121,3 +125,20 @@ def test_broadcast_invalidates_packed_weights():
     assert "probe" in m._pack_cache
     m.invalidate_packed()
     assert not m._pack_cache
+
+
+def test_dropped_grad_slice_is_cleared_not_inherited():
+    """after optimizer.zero_grad() (set_to_none) a parameter that gets NO gradient in the next step must not
+    inherit the previous step's averaged gradient from its slice of the flat buffer."""
+    from codon_amd import CODONNet16
+    from codon_amd.dist import GradSync
+    m = CODONNet16()
+    gs = GradSync(m)
+    gs.flat.fill_(5.0)                                  # "last step's" gradients
+    opt = torch.optim.SGD(gs.params, lr=0.1)
+    opt.zero_grad()                                     # every .grad is None; the flat buffer still holds the 5s
+    m.conv3.weight.grad = torch.full_like(m.conv3.weight, 2.0)       # only conv3 gets a gradient this step
+    gs.all_reduce_grads()
+    assert float(m.conv3.weight.grad.sum()) == 2.0 * m.conv3.weight.numel()
+    assert float(gs.flat.sum()) == 2.0 * m.conv3.weight.numel()      # nothing of the 5s survives
+    assert float(m.confuse.weight.grad.abs().sum()) == 0.0 and m.confuse.weight.grad._base is gs.flat

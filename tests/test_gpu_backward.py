@@ -124,6 +124,22 @@ def _relu_mask_flips(model_save, sd, x, y):
     return n
 
 
+def _hip_relu_masks(S):
+    """The ReLU masks of the HIP forward (its saved activations > 0), in the oracle forward's ReLU call order."""
+    on = lambda t: (t.cpu() > 0)
+    ms = [on(S["stem"]), on(S["in2"][:, :64]), on(S["stem_c"]), on(S["in2"][:, 64:])]
+    for i in range(5):
+        b = S[f"blk{i}"]
+        ms += [on(b["stage"][:, :64]), on(b["stage_c"][:, 64:]), on(b["stage"][:, 64:]), on(b["stage_c"][:, :64]),
+               on(b["r2"]), on(b["r2_c"])]
+    ms.append(on(S["fuse"]))
+    for i in range(3):
+        t = S[f"trunk{i}"]
+        ms += [on(t["stage"][:, :64]), on(t["stage"][:, 64:]), on(t["r2"])]
+    ms.append(on(S["t11"]))
+    return ms
+
+
 GRAD_CASES = ["kat0_x4_2x32x24", "kat0_x16_2x20x28", "he0_x4_2x24x20_taps", "he2_x16_1x21x27", "he1_x4_2x18x22"]
 FLIPS = {}     # case -> number of noise-level ReLU mask flips seen (0 = the strict per-tensor 1e-4 mode ran)
 
@@ -135,6 +151,7 @@ def test_gradients_match_reference_golden(name):
     m = _model(variant, sd)
     out = m(x.cuda(), y.cuda())
     mask_flips = _relu_mask_flips(out.grad_fn.saved, sd, x, y)
+    hip_masks = _hip_relu_masks(out.grad_fn.saved)
     FLIPS[name] = mask_flips
     print(f"[{name}] ReLU mask flips vs the oracle forward: {mask_flips} "
           f"({'strict per-tensor 1e-4' if mask_flips == 0 else 'per-tensor 5e-2 + whole-vector 1e-4'})")
@@ -173,16 +190,22 @@ def test_gradients_match_reference_golden(name):
     assert n == 44
     print(f"[{name}] worst per-tensor rel-RMSE {worst:.2e}, whole gradient vector {(num / den) ** 0.5:.2e}")
     assert (num / den) ** 0.5 <= GRAD_TOL     # whole gradient vector, flips or not
+    # DETERMINISTIC strict mode, whatever the flips: the oracle's autograd on the HIP forward's own ReLU masks and the
+    # same upstream gradient -- every tensor to 1e-4 (the oracle equals the reference's autograd wherever the masks
+    # agree: tests/test_oracle.py)
+    _, gforced, _ = orc.grads(sd, x, y, tgt, masks=hip_masks, upstream=g_up)
+    for k, p in m.named_parameters():
+        if k in gforced:
+            assert rel_rmse(p.grad.cpu(), gforced[k]) <= GRAD_TOL, (k, "forced masks")
 
 
 def test_golden_gradient_cases_strictness():
-    """At least 2 of the 5 golden gradient cases ran in strict per-tensor 1e-4 mode (measured on MI355X: he2_x16 and
-    he1_x4 see 0 flips; the other three see exactly 1 activation of ~1e-7 on the other side of zero), and no case
-    saw more than a handful of noise-level flips (runs after the parametrised test above, same process)."""
+    """Per-case BOUND on noise-level ReLU mask flips (each flip individually checked to be < 1e-6 on both sides by
+    _relu_mask_flips): how many cases see zero flips depends on summation order and may differ from box to box, so it
+    is printed, not asserted -- the strict per-tensor 1e-4 comparison runs for EVERY case on forced masks instead."""
     if set(FLIPS) != set(GRAD_CASES):
         pytest.skip("needs test_gradients_match_reference_golden to have run in this process")
-    strict = [k for k, v in FLIPS.items() if v == 0]
-    assert len(strict) >= 2, FLIPS
+    print("ReLU mask flips per case:", FLIPS)
     assert all(v <= 3 for v in FLIPS.values()), FLIPS
 
 
@@ -321,3 +344,51 @@ def test_training_steps_reduce_the_loss(dtype):
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16])
+def test_recompute_switch_gives_identical_gradients(dtype):
+    """model.set_recompute(): the 13 `stage` tensors are not kept, the backward re-runs the sibling convs from the saved
+    block inputs -- same kernels on the same operands, so every gradient is bit-identical and less memory is held."""
+    sd = orc.he_state("x4", seed=41)
+    g = np.random.default_rng(12)
+    B, H, W = 2, 40, 56
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32)).cuda()
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32)).cuda()
+    up = torch.from_numpy(g.standard_normal(size=(B, 1, H, W)).astype(np.float32)).cuda() / (B * H * W)
+    grads, peaks = [], []
+    for rec in (False, True):
+        m = _model("x4", sd)
+        if dtype is not None:
+            m.set_compute_dtype(dtype)
+        m.set_recompute(rec)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        out = m(x, y)
+        assert (out.grad_fn.saved["blk0"]["stage"] is None) == rec
+        out.backward(up)
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated())
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        del m, out
+    assert len(grads[0]) == 44 and all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+    assert peaks[1] < peaks[0]
+
+
+def test_packed_weight_verification_catches_data_writes(monkeypatch):
+    """A write through `.data` after the first forward does not bump Tensor._version, so the packed-weight cache cannot
+    see it (documented; model.invalidate_packed() is the remedy).  CODON_VERIFY_PACKED=1 turns the silent staleness
+    into an error."""
+    import codon_amd.model as M
+    sd = orc.he_state("x4", seed=43)
+    m = _model("x4", sd).eval()
+    x = torch.rand((1, 1, 16, 24), device="cuda")
+    with torch.no_grad():
+        o0 = m(x, x)
+        m.conv3.weight.data.mul_(0.5)            # the reference's own init idiom writes through .data (CODON_x4.py:50-53)
+        assert torch.equal(m(x, x), o0)          # stale packed weights: the documented hazard
+        monkeypatch.setattr(M, "VERIFY_PACKED", True)
+        with pytest.raises(RuntimeError, match="stale"):
+            m(x, x)
+        m.invalidate_packed()
+        assert not torch.equal(m(x, x), o0)

@@ -83,3 +83,32 @@ def test_state_dict_contract(golden_dir):
     for v in ("x4", "x8", "x16"):
         assert ref[v] == [(k, tuple(s)) for k, s in orc.state_shapes(v)]
     assert len(ref["x4"]) == 49 and len(ref["x16"]) == 44
+
+
+def test_forced_relu_masks_reproduce_the_plain_forward():
+    """oracle.forward(masks=...) with the forward's OWN masks is the plain forward (the forced-mask mode is what the GPU
+    gradient tests use to compare on identical ReLU masks)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import codon_oracle as orc
+    sd = orc.he_state("x4", seed=5)
+    x, y = orc.kat_inputs(1, 9, 11)
+    seen = []
+    relu = F.relu
+
+    def spy(z):
+        out = relu(z)
+        if z.dim() == 4:                 # the feature-map ReLUs; the gate MLPs' ReLUs (2-D) are not masked
+            seen.append(out > 0)
+        return out
+
+    F.relu = spy
+    try:
+        with torch.no_grad():
+            ref = orc.forward(sd, x, y)
+    finally:
+        F.relu = relu
+    assert len(seen) == 4 + 5 * 6 + 1 + 3 * 3 + 1
+    with torch.no_grad():
+        out = orc.forward(sd, x, y, masks=seen)
+    assert torch.equal(out, ref)
