@@ -38,10 +38,12 @@ def load(d, counters):
 
 def alg_bytes(name, P, es=2):
     """Bytes the kernel must move once per launch (16-bit activations: es = 2), or None."""
-    m = re.match(r"conv_c8_kernel<C8\w+, (\d), (\d+), (\d+), (true|false)>", name)
+    m = re.match(r"conv_c8_kernel<C8\w+, (\d), (\d+), (\d+), (true|false)(?:, \d+, (true|false))?>", name)
     if m:
-        k, ci, co, fuse = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true"
-        return None if fuse else (ci + co) * es * P       # FUSE: 128 in + 64 out (+128 mid when training saves it)
+        k, ci, co, fuse, gate = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true", m.group(5) == "true"
+        if fuse:
+            return (ci + 64) * es * P                     # inference: 128 in + 64 out (training also writes the 128-ch mid)
+        return ((2 if gate else 1) * ci + co) * es * P    # gated staging reads pre AND inputs; dgrad epilogues add mask / accumulate reads
     m = re.match(r"conv_mfma_bf16_kernel<\w+, (\d), (\d+), (\d+)", name)
     if m:
         return (int(m.group(2)) + int(m.group(3))) * es * P
