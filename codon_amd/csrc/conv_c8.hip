@@ -81,6 +81,9 @@ enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
 #ifndef CODON_C8_NW564
 #define CODON_C8_NW564 4
 #endif
+#ifndef CODON_C8_DMA
+#define CODON_C8_DMA 1     // stage x and weights by LDS-DMA (buffer_load_dwordx4 ... lds); 0: through registers (A/B)
+#endif
 template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_C8_PSEG3 : 2; };
 // waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
 template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : 4; };
@@ -168,22 +171,31 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
 
   // the next chunk's halo tile is requested in two halves, during the last two filter rows of the current chunk
   constexpr int XE1 = XE / 2, XEH = XE - XE1;
-  u32x4 xv[XEH];
+  constexpr bool DMA = (CODON_C8_DMA != 0) && !GATE;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  u32x4 xv[DMA ? 1 : XEH];
   u32x4 xg[GATE ? XEH : 1];
-  u32x4 wr[WE];
+  u32x4 wr[DMA ? 1 : WE];
 
-#define LOAD_X(chunk_, k0_, k1_)                                                        \
+#define LOAD_X(chunk_, buf_, k0_, k1_)                                                  \
   {                                                                                     \
     const unsigned so_ = (unsigned)(chunk_) * (unsigned)NCB * HW16;                     \
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
-      xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_);                                       \
-      if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, xoff[k], so_);                   \
+      if constexpr (DMA) {                                                              \
+        const unsigned vo_ = xoff[k];   /* passed as xoff[k] the host pass drops the kernel's stub (hipcc 7.2) */ \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(lds + (buf_) * XSP + k * NT + wave_u * 64), 16, \
+                                                 vo_, so_, 0, 0);                       \
+      } else {                                                                          \
+        xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_);                                     \
+        if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, xoff[k], so_);                 \
+      }                                                                                 \
     }                                                                                   \
   }
   // GATE: the staged vector is pre * (ch * sp) + inputs, formed in fp32 and rounded once -- the arithmetic of
   // cac_apply_c8_kernel followed by a plain load, bit for bit (out-of-image elements: 0 * g + 0 = 0)
 #define STORE_X(chunk_, buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */    \
-  {                                                                                     \
+  if constexpr (!DMA) {                                                                 \
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
       if constexpr (GATE) {                                                             \
         const float* cg_ = chs + ((((chunk_) * NCB + xcb[k]) * 8) & 63);                \
@@ -199,14 +211,20 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       }                                                                                 \
     }                                                                                   \
   }
-#define LOAD_W(stage_)                                                                  \
+#define LOAD_W(stage_, buf_)                                                            \
   {                                                                                     \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
-    _Pragma("unroll") for (int k = 0; k < WE; ++k)                                      \
-      wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16)); \
+    _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
+      if constexpr (DMA) {                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + k * NT + wave_u * 64), 16, \
+                                                 k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16), 0, 0); \
+      } else {                                                                          \
+        wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16)); \
+      }                                                                                 \
+    }                                                                                   \
   }
 #define STORE_W(buf_)                                                                   \
-  {                                                                                     \
+  if constexpr (!DMA) {                                                                 \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * NT] = wr[k];   \
   }
 
@@ -220,13 +238,14 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
 
   if constexpr (GATE) __syncthreads();        // chs
   if constexpr (XE1 > 0) {
-    LOAD_X(0, 0, XE1);
+    LOAD_X(0, 0, 0, XE1);
     STORE_X(0, 0, 0, XE1);
   }
-  LOAD_X(0, XE1, XE);
-  LOAD_W(0);
+  LOAD_X(0, 0, XE1, XE);
+  LOAD_W(0, 0);
   STORE_X(0, 0, XE1, XE);
   STORE_W(0);
+  if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this wave's pieces have landed
   __syncthreads();
 
   // stage (chunk, dy): weights of filter row dy for 16 channels in ws[(chunk*KS + dy) & 1], the chunk's halo tile in
@@ -242,11 +261,11 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       constexpr bool tail = (par == 1 && dy == KS - 1);           // last stage of the pair
       const bool has_next = !tail || (c2 + 2 < NCHUNK);
       if (has_next) {
-        LOAD_W(s + 1);
-        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, XE1, XE);
+        LOAD_W(s + 1, sbuf ^ 1);
+        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, par ^ 1, XE1, XE);
       }
       if constexpr (XE1 > 0 && dy == KS - 2) {
-        if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, 0, XE1);
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, par ^ 1, 0, XE1);
       }
 
       // operand fetch one filter tap ahead of its MFMAs, in two register sets.  PIN: sched_barrier holds that order
@@ -290,6 +309,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
         STORE_W(sbuf ^ 1);
         if constexpr (dy == KS - 1) STORE_X(chunk + 1, par ^ 1, XE1, XE);
       }
+      if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier: DMA pieces of the next stage are in LDS
       __syncthreads();
     });
   }
