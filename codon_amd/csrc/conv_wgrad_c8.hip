@@ -53,12 +53,23 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
   constexpr int XPITCH = ((XR * XC * 16 - pitch64 + 255) / 256) * 256 + pitch64;   // == 64 (mod 256), >= plane bytes
   constexpr int GPITCH = ((TH * TW * 16 - pitch64 + 255) / 256) * 256 + pitch64;
   static_assert(XPITCH >= XR * XC * 16 && GPITCH >= TH * TW * 16, "plane pitch covers the plane");
-  constexpr int XBYTES = XPL * XPITCH, GBYTES = GPL * GPITCH;
-  constexpr int NXE = XPL * XR * XC, NGE = GPL * TH * TW;   // 16-byte elements per tile
-  constexpr int XE = (NXE + NT - 1) / NT, GE = (NGE + NT - 1) / NT;
+  // k = 5: the tile is staged by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write).  A wave
+  // instruction fills 64 consecutive 16-byte slots, so each tensor's region is a run of 1 KiB pieces over its PITCHED planes;
+  // a lane carries the global offset of its slot, border and pitch-padding slots are out of range and land as zeros.
+  // Measured (same box): 5x5 128->128 7.23 -> 7.03 ms, 5x5 64->64 1.855 -> 1.84; the short tiles of k = 3 (0.985 -> 1.16 ms)
+  // and k = 1 (0.69 -> 0.71) lose -- they keep the register path (loads issued before the MFMAs, LDS written after them).
+  constexpr bool DMA = (KS == 5);
+  constexpr int XPS = XPITCH / 16, GPS = GPITCH / 16;       // plane pitch in slots
+  constexpr int XPIECES = (XPL * XPS + 63) / 64, GPIECES = (GPL * GPS + 63) / 64;
+  constexpr int XBYTES = XPIECES * 1024, GBYTES = GPIECES * 1024;
+  constexpr int NPIECE = XPIECES + GPIECES, NWV = NT / 64;
+  constexpr int PPW = (NPIECE + NWV - 1) / NWV;             // DMA: pieces per wave
+  constexpr int NXE = XPL * XR * XC, NGE = GPL * TH * TW;   // register path: 16-byte elements per tile
+  constexpr int XE = DMA ? 1 : (NXE + NT - 1) / NT, GE = DMA ? 1 : (NGE + NT - 1) / NT;
   constexpr int NK = TH * (TW / 16);
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (XBYTES + GBYTES)];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (XBYTES + GBYTES)];
+  typedef __attribute__((address_space(3))) void lds_void;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,12 +93,28 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
   const uint4* const xg = p.x + b * p.x_img + p.x_base + (long)cib * XPL * HW;
   const uint4* const gg = p.gy + b * p.g_img + p.g_base + (long)cob * GPL * HW;
 
-  // staging plan (tile independent): element e = tid + NT k = (plane, row, col)
+  // staging plan (tile independent): this wave's pieces wave, wave + NWV, ...; slot = piece * 64 + lane
+  unsigned rel[DMA ? PPW : 1];     // byte offset relative to the tile origin of the piece's tensor
+  int rc[DMA ? PPW : 1];           // (row << 8) | col inside the tile, or -1: padding slot (never loaded: lands as zero)
+#pragma unroll
+  for (int k = 0; k < (DMA ? PPW : 0); ++k) {
+    const int pc = wave + NWV * k;
+    const bool isx = pc < XPIECES;
+    const int s_ = (isx ? pc : pc - XPIECES) * 64 + lane;
+    const int ps = isx ? XPS : GPS, npl = isx ? XPL : GPL, pl_real = isx ? XR * XC : TH * TW, cols = isx ? XC : TW;
+    const int plane = s_ / ps, idx = s_ - plane * ps;
+    const bool in = pc < NPIECE && plane < npl && idx < pl_real;
+    const int r = idx / cols, q = idx - r * cols;
+    rel[k] = (unsigned)plane * HW16 + 16u * (unsigned)(r * W + q);
+    rc[k] = in ? ((r << 8) | q) : -1;
+  }
+
+  // register path: staging plan (tile independent): element e = tid + NT k = (plane, row, col)
   unsigned xrel[XE], grel[GE];      // byte offset relative to the tile origin
   int xrc[XE], grc[GE];             // (row << 8) | col, or -1 for the padding elements of the last round
   int xlds[XE], glds[GE];           // LDS byte address inside a buffer
 #pragma unroll
-  for (int k = 0; k < XE; ++k) {
+  for (int k = 0; k < (DMA ? 0 : XE); ++k) {
     const int e = tid + k * NT;
     const int q = e % XC, r = (e / XC) % XR, c = e / (XC * XR);
     const bool in = (NXE % NT == 0) || e < NXE;
@@ -96,7 +123,7 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
     xlds[k] = in ? c * XPITCH + (r * XC + q) * 16 : 0;
   }
 #pragma unroll
-  for (int k = 0; k < GE; ++k) {
+  for (int k = 0; k < (DMA ? 0 : GE); ++k) {
     const int e = tid + k * NT;
     const int q = e % TW, r = (e / TW) % TH, c = e / (TW * TH);
     const bool in = (NGE % NT == 0) || e < NGE;
@@ -118,6 +145,28 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
   for (int j = 0; j < NACC; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto stage_tile = [&](int t, int buf) {
+    const int ty = ty_begin + t / p.tiles_x, tx = t % p.tiles_x;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    // the tile origin (possibly before the slice start: such slots are masked) goes into the descriptor base
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xg + ((long)(ty0 - PAD) * W + (tx0 - PAD))), 0, (int)C8_OOB, C8_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gg + ((long)ty0 * W + tx0)), 0, (int)C8_OOB, C8_RSRC_FLAGS);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int pc = wave + NWV * k;               // wave-uniform
+      if (pc >= NPIECE) break;
+      const bool isx = pc < XPIECES;
+      const int pad = isx ? PAD : 0;
+      const int gy_ = ty0 - pad + (rc[k] >> 8), gx_ = tx0 - pad + (rc[k] & 255);
+      const bool ok = rc[k] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+      const unsigned vo_ = ok ? rel[k] : C8_OOB;
+      lds_void* dst = (lds_void*)(lds + buf * (XBYTES + GBYTES) + pc * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? xr : gr, dst, 16, vo_, 0, 0, 0);
+    }
+  };
 
   u32x4 xv[XE], gv[GE];
   auto load_tile = [&](int t) {
@@ -153,8 +202,13 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
   };
 
   if (ntile > 0) {
-    load_tile(0);
-    store_tile(0);
+    if constexpr (DMA) {
+      stage_tile(0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces have landed
+    } else {
+      load_tile(0);
+      store_tile(0);
+    }
   }
   __syncthreads();
 
@@ -162,7 +216,10 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const bool has_next = t + 1 < ntile;
-    if (has_next) load_tile(t + 1);
+    if (has_next) {
+      if constexpr (DMA) stage_tile(t + 1, (t + 1) & 1);
+      else load_tile(t + 1);
+    }
 
     const unsigned char* xs = lds + (t & 1) * (XBYTES + GBYTES);
     const unsigned char* gs = xs + XBYTES;
@@ -225,7 +282,8 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
       }
     }
 #undef WC8_READ
-    if (has_next) store_tile((t + 1) & 1);
+    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): the next tile's pieces of this wave have landed
+    else if (has_next) store_tile((t + 1) & 1);
     __syncthreads();
   }
 #undef TR_READ
