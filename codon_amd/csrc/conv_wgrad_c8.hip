@@ -27,6 +27,12 @@ namespace codon {
 
 constexpr int WC8_TH = 4;
 constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
+#ifndef CODON_WC8_CIT3
+#define CODON_WC8_CIT3 2
+#endif
+// k = 3: cin tiles per workgroup, each with its own 2*KS waves: 2 -> 64 cout x 64 cin, 12 waves = 3 per SIMD (balanced),
+// twice the MFMAs per staged byte and per barrier
+template <int KS> struct Wc8Cit { static constexpr int value = KS == 3 ? CODON_WC8_CIT3 : 1; };
 
 struct WgradC8Params {
   const uint4* x;
@@ -38,12 +44,13 @@ struct WgradC8Params {
 };
 
 template <class E, int KS>
-__global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
+__global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
   typedef typename E::vec8 vec8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr bool KSPLIT = (KS == 1);
-  constexpr int CIB = KSPLIT ? WC8_CIB1 : 1;     // 32-cin tiles per workgroup
-  constexpr int NT = KSPLIT ? 2 * WC8_TH * 64 : 2 * KS * 64;
+  constexpr int CIT = KSPLIT ? 1 : Wc8Cit<KS>::value;   // 32-cin tiles taken by separate wave groups
+  constexpr int CIB = KSPLIT ? WC8_CIB1 : CIT;          // 32-cin tiles per workgroup
+  constexpr int NT = KSPLIT ? 2 * WC8_TH * 64 : 2 * KS * CIT * 64;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = WC8_TH;
   constexpr int XC = KSPLIT ? TW : TW + 4;       // tile columns: origin tx0 - PAD; the 12-pixel windows reach column 35
@@ -132,12 +139,12 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
     glds[k] = in ? c * GPITCH + (r * TW + q) * 16 : 0;
   }
 
-  const int co_t = wave & 1, dy = KSPLIT ? 0 : (wave >> 1);
+  const int co_t = wave & 1, ci_t = KSPLIT ? 0 : (wave >> 1) % CIT, dy = KSPLIT ? 0 : (wave >> 1) / CIT;
   const int krow = wave >> 1;   // KSPLIT: the tile row whose k-steps this wave takes
   // transposing-read lane addresses: lane 4q+p of a 16-lane group supplies pixel q, channels 4p..4p+3 of the group's 16
   const int li = lane & 15, tq = li >> 2, tp = li & 3, cblk = (lane >> 4) & 1;
   const int a_lane = (co_t * 4 + 2 * cblk + (tp >> 1)) * GPITCH + (8 * half + tq) * 16 + (tp & 1) * 8;
-  const int b_lane = (2 * cblk + (tp >> 1)) * XPITCH + (dy * XC + 8 * half + tq) * 16 + (tp & 1) * 8;
+  const int b_lane = (ci_t * 4 + 2 * cblk + (tp >> 1)) * XPITCH + (dy * XC + 8 * half + tq) * 16 + (tp & 1) * 8;
 
   constexpr int NACC = KSPLIT ? CIB : KS;
   f32x16 acc[NACC];
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * 64, KS == 1 ? 
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx) {
     const int tap = dy * KS + dx;
-    const int ci = cib * 32 + l31;
+    const int ci = (cib * CIT + ci_t) * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cob * 64 + co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -340,7 +347,8 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   const int k = d->ksize, ci = d->cin, co = d->cout;
   if (!((k == 1 || k == 3 || k == 5) && ci % 32 == 0 && co % 64 == 0)) return false;
   if (k == 1 && ci % (32 * WC8_CIB1) != 0) return false;
-  pl->nchan_blocks = (co / 64) * (ci / (k == 1 ? 32 * WC8_CIB1 : 32));
+  if (k == 3 && ci % (32 * Wc8Cit<3>::value) != 0) return false;
+  pl->nchan_blocks = (co / 64) * (ci / (k == 1 ? 32 * WC8_CIB1 : k == 3 ? 32 * Wc8Cit<3>::value : 32));
   const int tiles_y = (d->height + WC8_TH - 1) / WC8_TH;
   int want = (WGRAD16_TARGET_BLOCKS + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);
   if (want < 1) want = 1;
@@ -384,8 +392,8 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
     if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, dim3(640), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, dim3(640), 0, stream, p);
   } else if (d->ksize == 3) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(384), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(384), 0, stream, p);
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(384 * Wc8Cit<3>::value), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(384 * Wc8Cit<3>::value), 0, stream, p);
   } else {
     if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
