@@ -171,16 +171,28 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
       if constexpr (GATE) spv[j] = buf_ld(sprsrc, poff[j], 0u);
     }
   }
-  float xg_[CK][PJ], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
+  // Round 3: x and weight stages go global -> LDS by LDS-DMA (buffer_load_dword / dwordx4 ... lds): no staging registers,
+  // no ds_write instructions, no lgkmcnt drain in front of the barrier.  Same box, same call: conv5x5-128 + chained 1x1
+  // 55.35 -> 53.67 ms (94.3 % -> 97.3 % of the fp32 MFMA peak), config-2 forward 1 005 -> 980 ms; bit-identical results.
+  // Lanes past the tile's last position are exec-masked (they would land in the next channel's plane); out-of-image
+  // positions carry an out-of-range offset and land as zeros.  k = 1 (0.385 -> 0.392 ms) and the gated staging (needs
+  // the VALU) keep the register path.  -DCODON_F32_DMA=0 restores it everywhere (A/B).
+#ifndef CODON_F32_DMA
+#define CODON_F32_DMA 1
+#endif
+  constexpr bool DMA = (CODON_F32_DMA != 0) && !GATE && KS != 1;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  float xg_[DMA ? 1 : CK][DMA ? 1 : PJ], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
 
   // weight stage: float4 element tid + 256 k of the stage; the padding round is out of range
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (W4 % NT == 0 || tid + (WE - 1) * NT < W4) ? wvo : BUF_OOB;
 
-  float4 wr[WE];
+  float4 wr[DMA ? 1 : WE];
 
 // staging steps as macros (not lambdas): keeps xr/wr in registers (no alloca left for scratch)
-#define LOAD_X(chunk_)                                                             \
+#define LOAD_X(chunk_, buf_)                                                       \
   {                                                                                \
     const __amdgpu_buffer_rsrc_t xr_ = planes(xbase, (chunk_) * CK, CK);           \
     __amdgpu_buffer_rsrc_t ir_;                                                    \
@@ -188,13 +200,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
     _Pragma("unroll") for (int c = 0; c < CK; ++c) {                               \
       if constexpr (GATE) chs[c] = chp[(((chunk_) * CK) & 63) + c];   /* wave-uniform: scalar load */ \
       _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                             \
-        xg_[c][j] = buf_ld(xr_, poff[j], (unsigned)c * HW4);                       \
-        if constexpr (GATE) xi_[c][j] = buf_ld(ir_, poff[j], (unsigned)c * HW4);   \
+        if constexpr (DMA) {                                                       \
+          const unsigned vo_ = poff[j];                                            \
+          if (NPOS % NT == 0 || tid + j * NT < NPOS)   /* exec-masked lanes write nothing */ \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_, (lds_void*)(lds + (buf_) * XSP + c * NPOS + j * NT + wave_u * 64), \
+                                                     4, vo_, (unsigned)c * HW4, 0, 0); \
+        } else {                                                                   \
+          xg_[c][j] = buf_ld(xr_, poff[j], (unsigned)c * HW4);                     \
+          if constexpr (GATE) xi_[c][j] = buf_ld(ir_, poff[j], (unsigned)c * HW4); \
+        }                                                                          \
       }                                                                            \
     }                                                                              \
   }
 #define STORE_X(buf_)                                                              \
-  {                                                                                \
+  if constexpr (!DMA) {                                                            \
     float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
     _Pragma("unroll") for (int j = 0; j < PJ; ++j)                                 \
       if (NPOS % NT == 0 || tid + j * NT < NPOS) {                                 \
@@ -204,16 +223,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
         }                                                                          \
       }                                                                            \
   }
-#define LOAD_W(stage_)                                                             \
+#define LOAD_W(stage_, buf_)                                                       \
   {                                                                                \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 4);                  \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                               \
-      const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0); \
-      wr[k] = *reinterpret_cast<const float4*>(&v_);                               \
+      if constexpr (DMA) {                                                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + (k * NT + wave_u * 64) * 4), \
+                                                 16, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0, 0); \
+      } else {                                                                     \
+        const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0); \
+        wr[k] = *reinterpret_cast<const float4*>(&v_);                             \
+      }                                                                            \
     }                                                                              \
   }
 #define STORE_W(buf_)                                                              \
-  {                                                                                \
+  if constexpr (!DMA) {                                                            \
     float4* dst_ = reinterpret_cast<float4*>(ws0 + (buf_) * WSP) + tid;            \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) dst_[k * NT] = wr[k];           \
   }
@@ -227,11 +251,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
   // prologue
-  LOAD_X(0);
-  LOAD_W(0);
+  LOAD_X(0, 0);
+  LOAD_W(0, 0);
   STORE_X(0);
   STORE_W(0);
   CODON_TSTAMP(p.dbg, 1)
+  if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's DMA pieces have landed
   __syncthreads();
   CODON_TSTAMP(p.dbg, 2)
 
@@ -241,8 +266,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
     const int dy = s - chunk * KS;
     const bool has_next = (s + 1 < NST);
     const bool next_chunk = has_next && (dy == KS - 1);
-    if (has_next) LOAD_W(s + 1);
-    if (next_chunk) LOAD_X(chunk + 1);
+    if (has_next) LOAD_W(s + 1, (s + 1) & 1);
+    if (next_chunk) LOAD_X(chunk + 1, (chunk + 1) & 1);
 
     // volatile: keeps every operand fetch a ds_read_b32 with a 16-bit immediate offset off ONE base register; left
     // alone, hipcc pairs them into ds_read2_b32 (8-bit offsets) and pays a v_add_u32 re-base per pair -- VALU ops
@@ -275,6 +300,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
 
     if (has_next) STORE_W((s + 1) & 1);
     if (next_chunk) STORE_X((chunk + 1) & 1);
+    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier
     __syncthreads();
   }
 
