@@ -7,10 +7,15 @@
  * function returns CODON_OK (0) or a negative codon_status; codon_last_error_string() gives
  * the detail for the calling thread.
  *
- * Activation layout: NCHW, contiguous, fp32 (CODON_F32), bf16 (CODON_BF16) or fp16 (CODON_F16).  A tensor
- * argument may be a channel slice of a wider buffer: (ctotal, coff) describe a buffer of
- * shape (B, ctotal, H, W) of which channels [coff, coff+C) are read/written -- this is how
- * the torch.cat calls of the reference (CODON_x4.py:79,80,85,119,125) disappear.
+ * Activation layout of the 64/128-channel tensors:
+ *   CODON_F32           : NCHW, contiguous                         element (b,c,h,w) at ((b*C + c)*H + h)*W + w
+ *   CODON_BF16 / _F16   : channel-blocked [B][C/8][H][W][8]        element (b,c,h,w) at (((b*C/8 + c/8)*H + h)*W + w)*8 + c%8
+ *                         (one 16-byte vector = 8 consecutive channels of a pixel: the MFMA B operand, codon_amd/csrc/c8.h)
+ * 1-channel maps (x, y, the output, gates, pooled maps) are fp32 NCHW in every mode: what crosses the reference's
+ * nn.Module boundary (CODON_x4.py:66-68,130-132) never changes layout.  A tensor argument may be a channel slice of a
+ * wider buffer: (ctotal, coff) describe a buffer of ctotal channels of which channels [coff, coff+C) are read / written
+ * (16-bit: coff, C and ctotal multiples of 8, i.e. whole 8-channel planes) -- this is how the torch.cat calls of the
+ * reference (CODON_x4.py:79,80,85,119,125) disappear.
  */
 #ifndef CODON_HIP_H
 #define CODON_HIP_H
@@ -64,8 +69,9 @@ typedef struct codon_conv_desc {
   int32_t dtype;              /* codon_dtype of x, y, residual and the packed weights              */
 } codon_conv_desc;
 
-/* A 64-channel activation that may be a channel slice of a wider NCHW buffer:
- * element (b, c, h, w) lives at data[((b*ctotal + coff + c)*H + h)*W + w]. */
+/* A 64-channel activation that may be a channel slice of a wider buffer.  fp32 (NCHW): element (b, c, h, w) lives at
+ * data[((b*ctotal + coff + c)*H + h)*W + w]; 16-bit (channel-blocked): at
+ * data[(((b*ctotal/8 + (coff + c)/8)*H + h)*W + w)*8 + (coff + c)%8]. */
 typedef struct codon_tensor {
   void* data;
   int32_t ctotal, coff;
