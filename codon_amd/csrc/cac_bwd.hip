@@ -200,6 +200,8 @@ __global__ __launch_bounds__(64) void partial_chunk_sum_kernel(float* __restrict
 // ---- C -------------------------------------------------------------------------------------------
 // g_pooled[c][q] = sum_{dy,dx} w[c][dy][dx] * g_z[q - (dy-2, dx-2)]
 // dW[c][dy][dx]  = sum_q g_z[q] * pooled[c][q + (dy-2, dx-2)]      (per-block partials)
+constexpr int SPB_PPT = 8;      // pixels per thread: the 50 weight-gradient partials are reduced over the wave ONCE per 8 pixels
+                                // (one pixel per thread spent its time in 50 x 6 shuffles: 0.67 ms for a 40 MB map)
 __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __restrict__ g_z,
                                                               const float* __restrict__ pooled,
                                                               const float* __restrict__ w,
@@ -211,44 +213,52 @@ __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 50) wsh[tid] = w[tid];
   __syncthreads();
-  const long idx = blockIdx.x * 256L + tid;
-  const bool live = idx < total;
   const long HW = (long)H * W;
-  int gx = 0, gy = 0, b = 0;
-  if (live) {
-    gx = (int)(idx % W);
-    const long t = idx / W;
-    gy = (int)(t % H);
-    b = (int)(t / H);
-  }
-  const float* gz = g_z + (long)b * HW;
-  const float* pl = pooled + (long)b * 2 * HW;
-  const float gq = live ? gz[(long)gy * W + gx] : 0.f;
-  float o0 = 0.f, o1 = 0.f;
+  float a0[25], a1[25];
 #pragma unroll
-  for (int dy = 0; dy < 5; ++dy) {
+  for (int t = 0; t < 25; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+#pragma unroll 1
+  for (int k = 0; k < SPB_PPT; ++k) {
+    const long idx = (blockIdx.x * (long)SPB_PPT + k) * 256 + tid;
+    const bool live = idx < total;
+    int gx = 0, gy = 0, b = 0;
+    if (live) {
+      gx = (int)(idx % W);
+      const long t = idx / W;
+      gy = (int)(t % H);
+      b = (int)(t / H);
+    }
+    const float* gz = g_z + (long)b * HW;
+    const float* pl = pooled + (long)b * 2 * HW;
+    const float gq = live ? gz[(long)gy * W + gx] : 0.f;
+    float o0 = 0.f, o1 = 0.f;
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) {
-      // transposed conv: neighbour at q - (dy-2, dx-2)
-      const int yy = gy - (dy - 2), xx = gx - (dx - 2);
-      if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float g = gz[(long)yy * W + xx];
-        o0 = fmaf(wsh[dy * 5 + dx], g, o0);
-        o1 = fmaf(wsh[25 + dy * 5 + dx], g, o1);
+    for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        // transposed conv: neighbour at q - (dy-2, dx-2)
+        const int yy = gy - (dy - 2), xx = gx - (dx - 2);
+        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const float g = gz[(long)yy * W + xx];
+          o0 = fmaf(wsh[dy * 5 + dx], g, o0);
+          o1 = fmaf(wsh[25 + dy * 5 + dx], g, o1);
+        }
+        // weight gradient: pooled at q + (dy-2, dx-2)
+        const int y2 = gy + (dy - 2), x2 = gx + (dx - 2);
+        const bool in2 = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+        a0[dy * 5 + dx] += in2 ? gq * pl[(long)y2 * W + x2] : 0.f;
+        a1[dy * 5 + dx] += in2 ? gq * pl[HW + (long)y2 * W + x2] : 0.f;
       }
-      // weight gradient: pooled at q + (dy-2, dx-2)
-      const int y2 = gy + (dy - 2), x2 = gx + (dx - 2);
-      const bool in2 = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-      float p0 = in2 ? gq * pl[(long)y2 * W + x2] : 0.f;
-      float p1 = in2 ? gq * pl[HW + (long)y2 * W + x2] : 0.f;
-      p0 = wsum(p0);
-      p1 = wsum(p1);
-      if (lane == 0) { red[dy * 5 + dx][wave] = p0; red[25 + dy * 5 + dx][wave] = p1; }
+    }
+    if (live) {
+      g_pooled[(long)b * 2 * HW + (long)gy * W + gx] = o0;
+      g_pooled[(long)b * 2 * HW + HW + (long)gy * W + gx] = o1;
     }
   }
-  if (live) {
-    g_pooled[(long)b * 2 * HW + (long)gy * W + gx] = o0;
-    g_pooled[(long)b * 2 * HW + HW + (long)gy * W + gx] = o1;
+#pragma unroll
+  for (int t = 0; t < 25; ++t) {
+    const float p0 = wsum(a0[t]), p1 = wsum(a1[t]);
+    if (lane == 0) { red[t][wave] = p0; red[25 + t][wave] = p1; }
   }
   __syncthreads();
   if (tid < 50) part_w[(long)blockIdx.x * 50 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
@@ -367,7 +377,7 @@ static const char* basep(const codon_tensor* t, long HW, int dtype) {
 }
 
 int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }
-int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W + 255) / 256); }
+int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W + 256 * SPB_PPT - 1) / (256 * SPB_PPT)); }
 
 int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
                    const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
