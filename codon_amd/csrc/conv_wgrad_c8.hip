@@ -34,6 +34,30 @@ constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
 // twice the MFMAs per staged byte and per barrier
 template <int KS> struct Wc8Cit { static constexpr int value = KS == 3 ? CODON_WC8_CIT3 : 1; };
 
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for_wc8(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_wc8<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+// Transposing LDS read as inline asm, for the LDS-DMA kernels: hipcc puts an `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 that follows a `buffer_load ... lds` (it cannot tell that the DMA fills the OTHER
+// buffer), which exposed the whole DMA latency once per tile (ISA of round 3's first DMA version; ablation: staging cost
+// 1.3 of 6.8 ms).  The asm form is invisible to that rule; its completion is tracked by hand (wc8_wait_lgkm: LDS
+// operations return in order, so "at most N younger reads outstanding" = the older ones have landed).
+template <int OFF>
+__device__ __forceinline__ s16x4 wc8_tr_read(unsigned addr) {
+  s16x4 d;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+  return d;
+}
+template <int N>
+__device__ __forceinline__ void wc8_wait_lgkm(s16x4& a0, s16x4& a1, s16x4& b0, s16x4& b1, s16x4& b2) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(b2) : "n"(N));
+}
+
 struct WgradC8Params {
   const uint4* x;
   const uint4* gy;
@@ -103,6 +127,7 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
   // staging plan (tile independent): this wave's pieces wave, wave + NWV, ...; slot = piece * 64 + lane
   unsigned rel[DMA ? PPW : 1];     // byte offset relative to the tile origin of the piece's tensor
   int rc[DMA ? PPW : 1];           // (row << 8) | col inside the tile, or -1: padding slot (never loaded: lands as zero)
+  unsigned reli[DMA ? PPW : 1];    // the offset an INTERIOR tile uses (no border tests): rel, or out of range for padding
 #pragma unroll
   for (int k = 0; k < (DMA ? PPW : 0); ++k) {
     const int pc = wave + NWV * k;
@@ -114,6 +139,7 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
     const int r = idx / cols, q = idx - r * cols;
     rel[k] = (unsigned)plane * HW16 + 16u * (unsigned)(r * W + q);
     rc[k] = in ? ((r << 8) | q) : -1;
+    reli[k] = in ? rel[k] : C8_OOB;
   }
 
   // register path: staging plan (tile independent): element e = tid + NT k = (plane, row, col)
@@ -161,6 +187,19 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
         (void*)(xg + ((long)(ty0 - PAD) * W + (tx0 - PAD))), 0, (int)C8_OOB, C8_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(gg + ((long)ty0 * W + tx0)), 0, (int)C8_OOB, C8_RSRC_FLAGS);
+    // 9 tiles in 10 touch no image border: their offsets are tile independent (3 instructions per piece instead of ~30)
+    const bool interior = ty0 >= PAD && ty0 + TH + PAD <= H && tx0 >= PAD && tx0 + TW + PAD <= W;   // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) {
+        const int pc = wave + NWV * k;             // wave-uniform
+        if (pc >= NPIECE) break;
+        const unsigned vo_ = reli[k];
+        lds_void* dst = (lds_void*)(lds + buf * (XBYTES + GBYTES) + pc * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pc < XPIECES ? xr : gr, dst, 16, vo_, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
       const int pc = wave + NWV * k;               // wave-uniform
@@ -208,14 +247,73 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
       if ((NGE % NT == 0) || tid + k * NT < NGE) *reinterpret_cast<u32x4*>(gs + glds[k]) = gv[k];
   };
 
-  if (ntile > 0) {
-    if constexpr (DMA) {
+  if constexpr (DMA) {
+    // Software pipeline over tiles: the barrier that publishes tile t+1 sits at the START of tile t's last k-step (after
+    // that step's operands are in registers = every read of buffer t&1 is done), so the first operands of tile t+1 are
+    // requested and the DMA of tile t+2 is issued BEHIND it, under the last step's MFMAs -- no drain at the tile edge.
+    static_assert(NK % 2 == 0, "operand sets alternate: the first k-step of every tile uses set 0");
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_void*)lds;
+    s16x4 a2[2][2], wd[2][3];
+    auto read_step = [&](auto kc, auto sc, unsigned ab, unsigned bb) {
+      constexpr int ks = decltype(kc)::value, set = decltype(sc)::value;
+      constexpr int r_ = ks / (TW / 16), c0_ = (ks % (TW / 16)) * 16;
+      constexpr int ao = XBYTES + (r_ * TW + c0_) * 16, bo = (r_ * XC + c0_) * 16;
+      a2[set][0] = wc8_tr_read<ao>(ab);
+      a2[set][1] = wc8_tr_read<ao + 64>(ab);
+      wd[set][0] = wc8_tr_read<bo>(bb);
+      wd[set][1] = wc8_tr_read<bo + 64>(bb);
+      wd[set][2] = wc8_tr_read<bo + 128>(bb);
+    };
+    if (ntile > 0) {
       stage_tile(0, 0);
       __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces have landed
-    } else {
-      load_tile(0);
-      store_tile(0);
+      __syncthreads();
+      read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds0 + a_lane, lds0 + b_lane);
+      if (ntile > 1) stage_tile(1, 1);
     }
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+      const unsigned cb = lds0 + (t & 1) * (XBYTES + GBYTES), nb = lds0 + ((t + 1) & 1) * (XBYTES + GBYTES);
+      static_for_wc8<NK>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        constexpr int cur = ks & 1;
+        if constexpr (ks + 1 < NK) {
+          read_step(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, cur ^ 1>{}, cb + a_lane, cb + b_lane);
+          wc8_wait_lgkm<5>(a2[cur][0], a2[cur][1], wd[cur][0], wd[cur][1], wd[cur][2]);
+        } else {
+          wc8_wait_lgkm<0>(a2[cur][0], a2[cur][1], wd[cur][0], wd[cur][1], wd[cur][2]);
+          __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this wave's pieces of tile t+1 have landed
+          __syncthreads();                     // ... everyone's have, and everyone is done reading buffer t & 1
+          if (t + 1 < ntile) read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{}, nb + a_lane, nb + b_lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        union { struct { s16x4 l, h; } s; vec8 v; } ua;
+        ua.s.l = a2[cur][0]; ua.s.h = a2[cur][1];
+        union { s16x4 v[3]; unsigned w[6]; } uw;
+        uw.v[0] = wd[cur][0]; uw.v[1] = wd[cur][1]; uw.v[2] = wd[cur][2];
+        const unsigned* w = uw.w;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const int m = dx / 2;
+          u32x4 f;
+          if (dx % 2 == 0) {
+            f = u32x4{w[m], w[m + 1], w[m + 2], w[m + 3]};
+          } else {
+            f = u32x4{__builtin_amdgcn_alignbit(w[m + 1], w[m], 16), __builtin_amdgcn_alignbit(w[m + 2], w[m + 1], 16),
+                      __builtin_amdgcn_alignbit(w[m + 3], w[m + 2], 16), __builtin_amdgcn_alignbit(w[m + 4], w[m + 3], 16)};
+          }
+          acc[dx] = E::mfma(ua.v, *reinterpret_cast<const vec8*>(&f), acc[dx]);
+        }
+        if constexpr (ks + 1 == NK) {            // behind the MFMAs: its address arithmetic runs beside them
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 2 < ntile) stage_tile(t + 2, t & 1);
+        }
+      });
+    }
+  } else {
+  if (ntile > 0) {
+    load_tile(0);
+    store_tile(0);
   }
   __syncthreads();
 
@@ -223,10 +321,7 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const bool has_next = t + 1 < ntile;
-    if (has_next) {
-      if constexpr (DMA) stage_tile(t + 1, (t + 1) & 1);
-      else load_tile(t + 1);
-    }
+    if (has_next) load_tile(t + 1);
 
     const unsigned char* xs = lds + (t & 1) * (XBYTES + GBYTES);
     const unsigned char* gs = xs + XBYTES;
@@ -289,11 +384,11 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
       }
     }
 #undef WC8_READ
-    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): the next tile's pieces of this wave have landed
-    else if (has_next) store_tile((t + 1) & 1);
+    if (has_next) store_tile((t + 1) & 1);
     __syncthreads();
   }
 #undef TR_READ
+  }   // !DMA
 
   float* __restrict__ wsp = p.ws + (long)split * (KS * KS) * p.cout * p.cin;
   if constexpr (KSPLIT) {
