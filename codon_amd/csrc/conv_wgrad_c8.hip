@@ -27,6 +27,9 @@ namespace codon {
 
 constexpr int WC8_TH = 4;
 constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
+#ifndef CODON_WC8_DMA3
+#define CODON_WC8_DMA3 1              // 0: k = 3 through the register path (A/B)
+#endif
 #ifndef CODON_WC8_CIT3
 #define CODON_WC8_CIT3 2
 #endif
@@ -84,12 +87,12 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
   constexpr int XPITCH = ((XR * XC * 16 - pitch64 + 255) / 256) * 256 + pitch64;   // == 64 (mod 256), >= plane bytes
   constexpr int GPITCH = ((TH * TW * 16 - pitch64 + 255) / 256) * 256 + pitch64;
   static_assert(XPITCH >= XR * XC * 16 && GPITCH >= TH * TW * 16, "plane pitch covers the plane");
-  // k = 5: the tile is staged by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write).  A wave
+  // k = 5 and k = 3: the tile is staged by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write).  A wave
   // instruction fills 64 consecutive 16-byte slots, so each tensor's region is a run of 1 KiB pieces over its PITCHED planes;
   // a lane carries the global offset of its slot, border and pitch-padding slots are out of range and land as zeros.
-  // Measured (same box): 5x5 128->128 7.23 -> 7.03 ms, 5x5 64->64 1.855 -> 1.84; the short tiles of k = 3 (0.985 -> 1.16 ms)
-  // and k = 1 (0.69 -> 0.71) lose -- they keep the register path (loads issued before the MFMAs, LDS written after them).
-  constexpr bool DMA = (KS == 5);
+  // Measured (same box, with the asm reads and the tile pipeline below): 5x5 128->128 6.76 -> 6.12 ms, 5x5 64->64 1.79 -> 1.61,
+  // 3x3 64->64 0.845 -> 0.77; the 2-k-step tiles of k = 1 (0.69 -> 0.71 with DMA) keep the register path.
+  constexpr bool DMA = CODON_WC8_DMA3 ? !KSPLIT : (KS == 5);
   constexpr int XPS = XPITCH / 16, GPS = GPITCH / 16;       // plane pitch in slots
   constexpr int XPIECES = (XPL * XPS + 63) / 64, GPIECES = (GPL * GPS + 63) / 64;
   constexpr int XBYTES = XPIECES * 1024, GBYTES = GPIECES * 1024;
