@@ -36,6 +36,13 @@ constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
 // k = 3: cin tiles per workgroup, each with its own 2*KS waves: 2 -> 64 cout x 64 cin, 12 waves = 3 per SIMD (balanced),
 // twice the MFMAs per staged byte and per barrier
 template <int KS> struct Wc8Cit { static constexpr int value = KS == 3 ? CODON_WC8_CIT3 : 1; };
+// k = 5: 2 x 5 (cout tile, filter row) waves would sit 3/3/2/2 on the four SIMDs (15 tap-MFMAs per k-step on the busy ones
+// against 12.5 on average).  The row waves therefore take taps dx = 0..3 only and two more waves (one per cout tile) take
+// the COLUMN dx = 4 of all five rows: 12 waves, 12/12/13/13 per SIMD (waves i, i+4, i+8 share a SIMD).
+template <int KS> struct Wc8Waves {
+  static constexpr int rows = 2 * KS * Wc8Cit<KS>::value;
+  static constexpr int value = KS == 1 ? 2 * WC8_TH : KS == 5 ? rows + 2 : rows;
+};
 
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void static_for_wc8(F&& f) {
@@ -56,9 +63,17 @@ __device__ __forceinline__ s16x4 wc8_tr_read(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
   return d;
 }
+// wait until at most N LDS reads are outstanding; the operands the caller is about to use are tied to the wait
 template <int N>
-__device__ __forceinline__ void wc8_wait_lgkm(s16x4& a0, s16x4& a1, s16x4& b0, s16x4& b1, s16x4& b2) {
-  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(b2) : "n"(N));
+__device__ __forceinline__ void wc8_wait_lgkm(s16x4 (&a)[2], s16x4 (&b)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wc8_wait_lgkm(s16x4 (&a)[2], s16x4 (&b)[10]) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]),
+                 "+v"(b[7]), "+v"(b[8]), "+v"(b[9])
+               : "n"(N));
 }
 
 struct WgradC8Params {
@@ -71,13 +86,15 @@ struct WgradC8Params {
 };
 
 template <class E, int KS>
-__global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
+__global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
   typedef typename E::vec8 vec8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr bool KSPLIT = (KS == 1);
   constexpr int CIT = KSPLIT ? 1 : Wc8Cit<KS>::value;   // 32-cin tiles taken by separate wave groups
   constexpr int CIB = KSPLIT ? WC8_CIB1 : CIT;          // 32-cin tiles per workgroup
-  constexpr int NT = KSPLIT ? 2 * WC8_TH * 64 : 2 * KS * CIT * 64;
+  constexpr int NT = Wc8Waves<KS>::value * 64;
+  constexpr bool BAL = (KS == 5);                      // row waves take KS-1 taps, two column waves the last one
+  constexpr int NROWW = Wc8Waves<KS>::rows, NTAP = BAL ? KS - 1 : KS;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = WC8_TH;
   constexpr int XC = KSPLIT ? TW : TW + 4;       // tile columns: origin tx0 - PAD; the 12-pixel windows reach column 35
@@ -168,7 +185,8 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
     glds[k] = in ? c * GPITCH + (r * TW + q) * 16 : 0;
   }
 
-  const int co_t = wave & 1, ci_t = KSPLIT ? 0 : (wave >> 1) % CIT, dy = KSPLIT ? 0 : (wave >> 1) / CIT;
+  const bool colrole = BAL && wave >= NROWW;      // wave-uniform
+  const int co_t = wave & 1, ci_t = KSPLIT || colrole ? 0 : (wave >> 1) % CIT, dy = KSPLIT || colrole ? 0 : (wave >> 1) / CIT;
   const int krow = wave >> 1;   // KSPLIT: the tile row whose k-steps this wave takes
   // transposing-read lane addresses: lane 4q+p of a 16-lane group supplies pixel q, channels 4p..4p+3 of the group's 16
   const int li = lane & 15, tq = li >> 2, tp = li & 3, cblk = (lane >> 4) & 1;
@@ -253,65 +271,88 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
   if constexpr (DMA) {
     // Software pipeline over tiles: the barrier that publishes tile t+1 sits at the START of tile t's last k-step (after
     // that step's operands are in registers = every read of buffer t&1 is done), so the first operands of tile t+1 are
-    // requested and the DMA of tile t+2 is issued BEHIND it, under the last step's MFMAs -- no drain at the tile edge.
+    // requested BEHIND it and the DMA of tile t+2 is issued after the last step's MFMAs -- no drain at the tile edge.
     static_assert(NK % 2 == 0, "operand sets alternate: the first k-step of every tile uses set 0");
     const unsigned lds0 = (unsigned)(unsigned long)(lds_void*)lds;
-    s16x4 a2[2][2], wd[2][3];
-    auto read_step = [&](auto kc, auto sc, unsigned ab, unsigned bb) {
-      constexpr int ks = decltype(kc)::value, set = decltype(sc)::value;
-      constexpr int r_ = ks / (TW / 16), c0_ = (ks % (TW / 16)) * 16;
-      constexpr int ao = XBYTES + (r_ * TW + c0_) * 16, bo = (r_ * XC + c0_) * 16;
-      a2[set][0] = wc8_tr_read<ao>(ab);
-      a2[set][1] = wc8_tr_read<ao + 64>(ab);
-      wd[set][0] = wc8_tr_read<bo>(bb);
-      wd[set][1] = wc8_tr_read<bo + 64>(bb);
-      wd[set][2] = wc8_tr_read<bo + 128>(bb);
-    };
-    if (ntile > 0) {
-      stage_tile(0, 0);
-      __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces have landed
-      __syncthreads();
-      read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds0 + a_lane, lds0 + b_lane);
-      if (ntile > 1) stage_tile(1, 1);
-    }
+    auto run = [&](auto rolec) {
+      constexpr bool COL = decltype(rolec)::value;          // column wave (BAL): tap dx = KS-1 of every filter row
+      constexpr int NB = COL ? 2 * KS : 3;                  // B reads per k-step
+      s16x4 a2[2][2], wb[2][NB];
+      auto read_step = [&](auto kc, auto sc, unsigned ab, unsigned bb) {
+        constexpr int ks = decltype(kc)::value, set = decltype(sc)::value;
+        constexpr int r_ = ks / (TW / 16), c0_ = (ks % (TW / 16)) * 16;
+        constexpr int ao = XBYTES + (r_ * TW + c0_) * 16, bo = (r_ * XC + c0_) * 16;
+        a2[set][0] = wc8_tr_read<ao>(ab);
+        a2[set][1] = wc8_tr_read<ao + 64>(ab);
+        static_for_wc8<NB>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          // row wave: pixels 0..11 of its row; column wave: pixels 4..11 (elements KS-1 .. KS+6) of row j/2
+          constexpr int off = COL ? bo + (j / 2) * XC * 16 + 64 + (j % 2) * 64 : bo + j * 64;
+          wb[set][j] = wc8_tr_read<off>(bb);
+        });
+      };
+      if (ntile > 0) {
+        stage_tile(0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this wave's pieces have landed
+        __syncthreads();
+        read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds0 + a_lane, lds0 + b_lane);
+        if (ntile > 1) stage_tile(1, 1);
+      }
 #pragma unroll 1
-    for (int t = 0; t < ntile; ++t) {
-      const unsigned cb = lds0 + (t & 1) * (XBYTES + GBYTES), nb = lds0 + ((t + 1) & 1) * (XBYTES + GBYTES);
-      static_for_wc8<NK>([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        constexpr int cur = ks & 1;
-        if constexpr (ks + 1 < NK) {
-          read_step(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, cur ^ 1>{}, cb + a_lane, cb + b_lane);
-          wc8_wait_lgkm<5>(a2[cur][0], a2[cur][1], wd[cur][0], wd[cur][1], wd[cur][2]);
-        } else {
-          wc8_wait_lgkm<0>(a2[cur][0], a2[cur][1], wd[cur][0], wd[cur][1], wd[cur][2]);
-          __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this wave's pieces of tile t+1 have landed
-          __syncthreads();                     // ... everyone's have, and everyone is done reading buffer t & 1
-          if (t + 1 < ntile) read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{}, nb + a_lane, nb + b_lane);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        union { struct { s16x4 l, h; } s; vec8 v; } ua;
-        ua.s.l = a2[cur][0]; ua.s.h = a2[cur][1];
-        union { s16x4 v[3]; unsigned w[6]; } uw;
-        uw.v[0] = wd[cur][0]; uw.v[1] = wd[cur][1]; uw.v[2] = wd[cur][2];
-        const unsigned* w = uw.w;
-#pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-          const int m = dx / 2;
-          u32x4 f;
-          if (dx % 2 == 0) {
-            f = u32x4{w[m], w[m + 1], w[m + 2], w[m + 3]};
+      for (int t = 0; t < ntile; ++t) {
+        const unsigned cb = lds0 + (t & 1) * (XBYTES + GBYTES), nb = lds0 + ((t + 1) & 1) * (XBYTES + GBYTES);
+        static_for_wc8<NK>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          constexpr int cur = ks & 1;
+          if constexpr (ks + 1 < NK) {
+            read_step(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, cur ^ 1>{}, cb + a_lane, cb + b_lane);
+            wc8_wait_lgkm<2 + NB>(a2[cur], wb[cur]);
           } else {
-            f = u32x4{__builtin_amdgcn_alignbit(w[m + 1], w[m], 16), __builtin_amdgcn_alignbit(w[m + 2], w[m + 1], 16),
-                      __builtin_amdgcn_alignbit(w[m + 3], w[m + 2], 16), __builtin_amdgcn_alignbit(w[m + 4], w[m + 3], 16)};
+            wc8_wait_lgkm<0>(a2[cur], wb[cur]);
+            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this wave's pieces of tile t+1 have landed
+            __syncthreads();                     // ... everyone's have, and everyone is done reading buffer t & 1
+            if (t + 1 < ntile) read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{}, nb + a_lane, nb + b_lane);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          acc[dx] = E::mfma(ua.v, *reinterpret_cast<const vec8*>(&f), acc[dx]);
-        }
-        if constexpr (ks + 1 == NK) {            // behind the MFMAs: its address arithmetic runs beside them
-          __builtin_amdgcn_sched_barrier(0);
-          if (t + 2 < ntile) stage_tile(t + 2, t & 1);
-        }
-      });
+          union { struct { s16x4 l, h; } s; vec8 v; } ua;
+          ua.s.l = a2[cur][0]; ua.s.h = a2[cur][1];
+          if constexpr (COL) {
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+              union { struct { s16x4 l, h; } s; vec8 v; } ub;
+              ub.s.l = wb[cur][2 * r]; ub.s.h = wb[cur][2 * r + 1];
+              acc[r] = E::mfma(ua.v, ub.v, acc[r]);
+            }
+          } else {
+            // window words w[0..5] = pixels 0 .. 11 past (row, c0 + 8h) of the lane's channel; tap dx = elements dx .. dx+7
+            union { s16x4 v[3]; unsigned w[6]; } uw;
+            uw.v[0] = wb[cur][0]; uw.v[1] = wb[cur][1]; uw.v[2] = wb[cur][2];
+            const unsigned* w = uw.w;
+#pragma unroll
+            for (int dx = 0; dx < NTAP; ++dx) {
+              const int m = dx / 2;
+              u32x4 f;
+              if (dx % 2 == 0) {
+                f = u32x4{w[m], w[m + 1], w[m + 2], w[m + 3]};
+              } else {
+                f = u32x4{__builtin_amdgcn_alignbit(w[m + 1], w[m], 16), __builtin_amdgcn_alignbit(w[m + 2], w[m + 1], 16),
+                          __builtin_amdgcn_alignbit(w[m + 3], w[m + 2], 16), __builtin_amdgcn_alignbit(w[m + 4], w[m + 3], 16)};
+              }
+              acc[dx] = E::mfma(ua.v, *reinterpret_cast<const vec8*>(&f), acc[dx]);
+            }
+          }
+          if constexpr (ks + 1 == NK) {            // behind the MFMAs: its address arithmetic runs beside them
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntile) stage_tile(t + 2, t & 1);
+          }
+        });
+      }
+    };
+    if constexpr (BAL) {
+      if (colrole) run(std::true_type{});
+      else run(std::false_type{});
+    } else {
+      run(std::false_type{});
     }
   } else {
   if (ntile > 0) {
@@ -417,13 +458,14 @@ __global__ __launch_bounds__(KS == 1 ? 2 * WC8_TH * 64 : 2 * KS * Wc8Cit<KS>::va
     return;
   }
 #pragma unroll
-  for (int dx = 0; dx < KS; ++dx) {
-    const int tap = dy * KS + dx;
+  for (int j = 0; j < KS; ++j) {
+    if (BAL && !colrole && j >= NTAP) break;
+    const int tap = colrole ? j * KS + (KS - 1) : dy * KS + j;      // column wave: accumulator j = filter row j, dx = KS-1
     const int ci = (cib * CIT + ci_t) * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cob * 64 + co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      wsp[((long)tap * p.cout + co) * p.cin + ci] = acc[dx][r];
+      wsp[((long)tap * p.cout + co) * p.cin + ci] = acc[j][r];
     }
   }
 }
@@ -487,11 +529,11 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
   const bool f16 = d->dtype == CODON_F16;
   if (d->ksize == 5) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, dim3(640), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, dim3(640), 0, stream, p);
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, dim3(Wc8Waves<5>::value * 64), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, dim3(Wc8Waves<5>::value * 64), 0, stream, p);
   } else if (d->ksize == 3) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(384 * Wc8Cit<3>::value), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(384 * Wc8Cit<3>::value), 0, stream, p);
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(Wc8Waves<3>::value * 64), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(Wc8Waves<3>::value * 64), 0, stream, p);
   } else {
     if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
