@@ -44,7 +44,7 @@ int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, f
 int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*, const void*, const codon_tensor*,
                          const codon_tensor*, float*, float*, int, hipStream_t);
 int conv2d_gated_fwd_16(const codon_conv_desc*, const void*, const codon_tensor*, const float*, const float*, const void*,
-                        void*, hipStream_t);
+                        void*, const codon_tensor*, hipStream_t);
 int cac_fused_tiles(int, int);
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -244,8 +244,8 @@ int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, cons
                         pools_out, (hipStream_t)stream);
 }
 
-int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
-                           const float* sp, const void* w_packed, void* y, codon_stream_t stream) {
+static int gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                     const float* sp, const void* w_packed, void* y, const codon_tensor* gated_out, codon_stream_t stream) {
   CODON_REQUIRE(d && pre && inputs && inputs->data && ch && sp && w_packed && y, CODON_ERR_BAD_ARG,
                 "conv2d_gated_fwd: null pointer");
   CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_gated_fwd: bad shape %dx%dx%d",
@@ -260,9 +260,23 @@ int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codo
   CODON_REQUIRE((d->flags & ~CODON_CONV_RELU) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: only the RELU flag applies");
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_gated_fwd: packed weights not 16-byte aligned");
   if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
-    return conv2d_gated_fwd_16(d, pre, inputs, ch, sp, w_packed, y, (hipStream_t)stream);
+    return conv2d_gated_fwd_16(d, pre, inputs, ch, sp, w_packed, y, gated_out, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: dtype %d", d->dtype);
+  CODON_REQUIRE(gated_out == nullptr, CODON_ERR_UNSUPPORTED,
+                "conv2d_gated_emit_fwd: 16-bit only (the fp32 gated convs are matrix-pipe bound: their staging arithmetic is hidden)");
   return conv2d_gated_fwd_f32(d, (const float*)pre, inputs, ch, sp, (const float*)w_packed, (float*)y, (hipStream_t)stream);
+}
+
+int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                           const float* sp, const void* w_packed, void* y, codon_stream_t stream) {
+  return gated_fwd(d, pre, inputs, ch, sp, w_packed, y, nullptr, stream);
+}
+
+int codon_conv2d_gated_emit_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                                const float* sp, const void* w_packed, void* y, const codon_tensor* gated_out,
+                                codon_stream_t stream) {
+  CODON_REQUIRE(gated_out && gated_out->data, CODON_ERR_BAD_ARG, "conv2d_gated_emit_fwd: null gated_out");
+  return gated_fwd(d, pre, inputs, ch, sp, w_packed, y, gated_out, stream);
 }
 
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {

@@ -45,6 +45,8 @@ struct ConvC8Params {
   long g_img, g_base;
   const float* gch;     // (B,64) channel gate: channel c of the slice uses gch[c & 63]
   const float* gsp;     // (B,1,H,W) spatial gate
+  uint4* gout;          // optional: the gate-applied input itself is ALSO written here (each tile its own pixels), so a
+  long go_img, go_base; // sibling conv on the same input can run plain (codon_conv2d_gated_emit_fwd)
   // FUSE only, optional (st_pool != nullptr): CAC statistics of the 64 channels this launch produces, from the epilogue
   float* st_pool;       // (B,2,H,W): per pixel { max, SUM } over this stream's 64 channels (ChannelPool, CAC_module.py:81)
   float* st_part;       // (B, tiles, 128, 2): per tile, per channel { sum, max } (first stage of the pools, :43,47)
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   unsigned xoff[XE];
   int xcb[GATE ? XE : 1];        // GATE: plane (0 / 1) of the element inside its chunk, and its pixel's spatial gate
   float xsp[GATE ? XE : 1];
+  unsigned xown = 0;             // GATE: bit k = element k is one of the tile's OWN pixels (not halo), inside the image
   {
     constexpr int DQ = NT % XQ, DR = (NT / XQ) % XR, DC = (NT / XQ) / XR;
     int cb = tid / (XR * XQ);
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
         xcb[k] = cb & 1;
         const float g_ = p.gsp[(long)b * H * W + (ok ? gy * W + gx : 0)];
         xsp[k] = ok ? g_ : 0.f;
+        if (ok && r >= PAD && r < PAD + TH && q >= PAD && q < PAD + TW) xown |= 1u << k;
       }
       q += DQ; r += DR; cb += DC;
       if (q >= XQ) { q -= XQ; r += 1; }
@@ -162,6 +166,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   }
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(GATE ? p.gin + (long)b * p.g_img + p.g_base : p.x), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
+  const bool emit = GATE && p.gout != nullptr;           // wave-uniform
+  const __amdgpu_buffer_rsrc_t gorsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(emit ? p.gout + (long)b * p.go_img + p.go_base : (uint4*)p.y), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
   const lds_w128 xwr = (lds_w128)(xs0 + tid);
   const unsigned wvo = (unsigned)tid * 16u;
   const unsigned wvo_last = (WS % NT == 0 || tid + (WE - 1) * NT < WS) ? wvo : C8_OOB;
@@ -205,7 +212,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
         c8_unpack<E>(xv[k - (k0_)], v_);                                                \
         c8_unpack<E>(xg[k - (k0_)], q_);                                                \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) v_[j] = fmaf(v_[j], cg8_[j] * xsp[k], q_[j]); \
-        xwr[(buf_) * XSP + k * NT] = c8_pack<E>(v_);                                    \
+        const u32x4 pv_ = c8_pack<E>(v_);                                               \
+        xwr[(buf_) * XSP + k * NT] = pv_;                                               \
+        if (emit) c8_st(pv_, gorsrc, ((xown >> k) & 1u) ? xoff[k] : C8_OOB, (unsigned)(chunk_) * (unsigned)NCB * HW16); \
       } else {                                                                          \
         xwr[(buf_) * XSP + k * NT] = xv[k - (k0_)];                                     \
       }                                                                                 \
@@ -737,6 +746,7 @@ static void c8_fill(ConvC8Params& p, const codon_conv_desc* d, const void* x, co
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.st_pool = nullptr; p.st_part = nullptr; p.st_choff = 0;
   p.gin = nullptr; p.g_img = p.g_base = 0; p.gch = nullptr; p.gsp = nullptr;
+  p.gout = nullptr; p.go_img = p.go_base = 0;
 }
 
 template <class E, int CIN, int COUT>
@@ -834,7 +844,7 @@ static int conv2d_gated_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_
 }
 
 int conv2d_gated_fwd_16(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
-                        const float* sp, const void* w, void* y, hipStream_t stream) {
+                        const float* sp, const void* w, void* y, const codon_tensor* gated_out, hipStream_t stream) {
   CODON_REQUIRE(c8_desc_ok(d, false) && c8_slice_ok(inputs->ctotal, inputs->coff, d->cin), CODON_ERR_BAD_ARG,
                 "conv2d_gated_fwd: 16-bit tensors are channel-blocked: ctotal / coff / channels multiples of 8");
   const long HW = (long)d->height * d->width;
@@ -844,6 +854,12 @@ int conv2d_gated_fwd_16(const codon_conv_desc* d, const void* pre, const codon_t
   c8_fill(p, d, pre, w, y, nullptr);
   p.gin = (const uint4*)inputs->data; p.g_img = (inputs->ctotal / 8) * HW; p.g_base = (inputs->coff / 8) * HW;
   p.gch = ch; p.gsp = sp;
+  if (gated_out != nullptr) {
+    CODON_REQUIRE(gated_out->data != nullptr && c8_slice_ok(gated_out->ctotal, gated_out->coff, d->cin), CODON_ERR_BAD_ARG,
+                  "conv2d_gated_emit_fwd: gated_out slice [%d,%d) of %d channels", gated_out->coff,
+                  gated_out->coff + d->cin, gated_out->ctotal);
+    p.gout = (uint4*)gated_out->data; p.go_img = (gated_out->ctotal / 8) * HW; p.go_base = (gated_out->coff / 8) * HW;
+  }
   return d->dtype == CODON_F16 ? conv2d_gated_c8<C8F16>(p, d, stream) : conv2d_gated_c8<C8Bf16>(p, d, stream);
 }
 

@@ -27,6 +27,9 @@ import os as _os
 
 # inference, 16-bit tensors: form the gate-apply in the consuming convs' staging (True) or as a pass (False); A/B switch
 GATED_16BIT = _os.environ.get("CODON_GATED16", "1") != "0"
+# 16-bit gated inference: the conv5x5 of a sibling pair applies the gate and EMITS the gated tensor, the conv3x3 reads it as
+# a plain conv (its staging is bound by the gate arithmetic otherwise: 1.00 vs 0.71 ms at 32x480x640).  0 = both gated (A/B)
+GATED_EMIT = _os.environ.get("CODON_GATED_EMIT", "1") != "0"
 # debug: re-pack on every cache hit and compare, so a write through `.data` after the first forward (the reference's own
 # init idiom is m.weight.data.normal_(), CODON_x4.py:50-53) raises instead of silently using stale packed weights
 VERIFY_PACKED = _os.environ.get("CODON_VERIFY_PACKED", "0") != "0"
@@ -272,10 +275,16 @@ class _CODONBase(nn.Module):
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
         gated = (not keep) and not split5 and (adt == torch.float32 or GATED_16BIT)
 
-        def gconv(gate, pre_s, in_s, plain_s, name, ys, k):
-            """relu(conv_k(gate-applied input)): `gate` = (ch, sp) of the producing block or None (plain input)."""
-            if gate is not None:
-                ops.conv2d_gated(pre_s, in_s, gate[0], gate[1], P(name), ys, k, relu=True)
+        emit16 = gated and fused_stats and GATED_EMIT
+        xg = new(128) if emit16 else None      # [out | out_c] as emitted by the gated conv5x5s of a block
+
+        def gconv(gate, pre_s, in_s, plain_s, name, ys, k, emit=None, emitted=None):
+            """relu(conv_k(gate-applied input)): `gate` = (ch, sp) of the producing block or None (plain input).
+            emit: this conv also writes the gated input there; emitted: a sibling already did -- run plain on it."""
+            if gate is not None and emitted is not None:
+                conv(emitted, name, ys, k, relu=True)
+            elif gate is not None:
+                ops.conv2d_gated(pre_s, in_s, gate[0], gate[1], P(name), ys, k, relu=True, emit=emit)
             else:
                 conv(plain_s, name, ys, k, relu=True)
 
@@ -317,13 +326,14 @@ class _CODONBase(nn.Module):
             pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
             gate = prev_gate if (gated and i > 0) else None      # (ch, sp) of block i-1: its apply runs in our staging
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
-            gconv(gate, pre, inputs, out, "conv1", Slice(stage, 0, 64), 3)
-            gconv(gate, pre, inputs, out, "conv2", Slice(stage, 64, 64), 5)
+            xg_d, xg_c = (Slice(xg, 0, 64), Slice(xg, 64, 64)) if emit16 else (None, None)
+            gconv(gate, pre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
+            gconv(gate, pre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
             conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
                       stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
-            gconv(gate, pre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5)
-            gconv(gate, pre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3)
+            gconv(gate, pre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
+            gconv(gate, pre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
             conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
                       stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91

@@ -206,8 +206,9 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
 
 
 def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, w_packed: torch.Tensor, y: Slice,
-                 ksize: int, relu: bool = False):
-    """y = conv(pre * (ch * sp) + inputs) [relu]: the CAC gate-apply of the producing block formed while staging."""
+                 ksize: int, relu: bool = False, emit: Optional[Slice] = None):
+    """y = conv(pre * (ch * sp) + inputs) [relu]: the CAC gate-apply of the producing block formed while staging.
+    emit (16-bit): the gated input itself is also written there, for the sibling conv on the same input."""
     lib = L.load()
     dev = _dev(pre.buf, inputs.buf, ch, sp, w_packed, y.buf)
     B, H, W = _bhw(pre.buf)
@@ -218,8 +219,15 @@ def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, 
                    L.CONV_RELU if relu else 0, _dt(pre.buf))
     it = inputs.ct()
     with torch.cuda.device(dev):
-        L.check(lib.codon_conv2d_gated_fwd(C.byref(d), _ptr(pre.buf), C.byref(it), _ptr(ch), _ptr(sp), _ptr(w_packed),
-                                           _ptr(y.buf), _stream(dev)), "conv2d_gated_fwd")
+        if emit is not None:
+            assert emit.c == pre.c and _bhw(emit.buf) == (B, H, W) and emit.buf.dtype == pre.buf.dtype
+            et = emit.ct()
+            L.check(lib.codon_conv2d_gated_emit_fwd(C.byref(d), _ptr(pre.buf), C.byref(it), _ptr(ch), _ptr(sp),
+                                                    _ptr(w_packed), _ptr(y.buf), C.byref(et), _stream(dev)),
+                    "conv2d_gated_emit_fwd")
+        else:
+            L.check(lib.codon_conv2d_gated_fwd(C.byref(d), _ptr(pre.buf), C.byref(it), _ptr(ch), _ptr(sp), _ptr(w_packed),
+                                               _ptr(y.buf), _stream(dev)), "conv2d_gated_fwd")
 
 
 def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: bool = False):

@@ -147,6 +147,14 @@ int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, cons
  * bit.  Any dtype, (k, cin, cout) in {(5,64,64), (3,64,64), (3,128,64)}. */
 int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
                            const float* sp, const void* w_packed, void* y, codon_stream_t stream);
+/* The same conv, which ALSO writes its gate-applied input x (the d->cin channels, each workgroup the pixels of its own
+ * tile, the values it staged) to the `gated_out` slice: `out` / `out_c` feed TWO convs (conv1 + conv2, conv4 + conv5,
+ * CODON_x4.py:75-78) -- the first one applies the gate and emits x, the second reads it as a plain conv (codon_conv2d_fwd)
+ * instead of repeating the gate arithmetic in its own staging.  gated_out must not alias `pre` / `inputs` (other tiles
+ * still read their halos from them).  16-bit dtypes only (CODON_ERR_UNSUPPORTED for fp32). */
+int codon_conv2d_gated_emit_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
+                                const float* sp, const void* w_packed, void* y, const codon_tensor* gated_out,
+                                codon_stream_t stream);
 
 /* dL/dw (cout, cin, k, k) fp32 = sum over b,h,w of gy[b,co,h,w] * x[b,ci,h+dy-p,w+dx-p]: what autograd
  * computes for the nn.Conv2d weights (the reference has no explicit backward).

@@ -285,3 +285,39 @@ def test_gated_conv_equals_apply_then_conv(kcc, dtype):
         ops.conv2d(Slice(oc, off, cin), wp, Slice(y0), k, relu=True)
         ops.conv2d_gated(Slice(pre2, off, cin), Slice(in2, off, cin), ch, sp, wp, Slice(y1), k, relu=True)
         assert torch.equal(y0, y1)
+        # emit: the same conv also writes the gated input it staged -- every pixel of every channel exactly once,
+        # == cac_apply's output bit for bit, into a slice of a wider buffer whose other channels stay untouched
+        y2 = ops.new_act(B, cout, H, W, dtype, dev).fill_(float("nan"))
+        xg = ops.new_act(B, 128 + cin, H, W, dtype, dev).fill_(float("nan"))
+        ops.conv2d_gated(Slice(pre2, off, cin), Slice(in2, off, cin), ch, sp, wp, Slice(y2), k, relu=True,
+                         emit=Slice(xg, 64, cin))
+        assert torch.equal(y0, y2)
+        got, want = ops.to_nchw(xg), ops.to_nchw(oc)
+        assert torch.equal(got[:, 64:64 + cin], want[:, off:off + cin])
+        assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 64 + cin:]).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_inference_schedules_agree_bit_for_bit(dtype):
+    """16-bit inference has three schedules for `out*ad_CAC + inputs` (CODON_x4.py:89-91): a cac_apply pass, both sibling
+    convs gated, or the conv5x5 gated + emitting and the conv3x3 plain on the emitted tensor (the default).  Same
+    arithmetic, same rounding points: identical outputs."""
+    import codon_amd
+    from codon_amd import model as M
+    dev = _dev()
+    torch.manual_seed(3)
+    net = codon_amd.CODONNet().to(dev)
+    net.set_compute_dtype(dtype)
+    x = torch.rand((2, 1, 37, 70), device=dev)
+    y = torch.rand((2, 1, 37, 70), device=dev)
+    outs = []
+    old = (M.GATED_16BIT, M.GATED_EMIT)
+    try:
+        for g16, emit in ((True, True), (True, False), (False, False)):
+            M.GATED_16BIT, M.GATED_EMIT = g16, emit
+            with torch.no_grad():
+                outs.append(net(x, y).clone())
+    finally:
+        M.GATED_16BIT, M.GATED_EMIT = old
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
