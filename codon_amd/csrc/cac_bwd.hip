@@ -200,59 +200,74 @@ __global__ __launch_bounds__(64) void partial_chunk_sum_kernel(float* __restrict
 // ---- C -------------------------------------------------------------------------------------------
 // g_pooled[c][q] = sum_{dy,dx} w[c][dy][dx] * g_z[q - (dy-2, dx-2)]
 // dW[c][dy][dx]  = sum_q g_z[q] * pooled[c][q + (dy-2, dx-2)]      (per-block partials)
-constexpr int SPB_PPT = 8;      // pixels per thread: the 50 weight-gradient partials are reduced over the wave ONCE per 8 pixels
-                                // (one pixel per thread spent its time in 50 x 6 shuffles: 0.67 ms for a 40 MB map)
+// A 32 x 32 pixel tile per workgroup: g_z and the two pooled planes are staged ONCE with their 2-pixel halo (zeros outside
+// the image: every border condition of the two sums becomes a zero operand), the 75 operand reads per pixel come from LDS
+// (one global load per pixel and tap cost 0.67 - 1.07 ms for a 40 MB map in rounds 2 - 3; the three planes are 0.12 GB).
+// A thread owns 4 consecutive pixels of one column and keeps the 50 weight-gradient partials in registers;
+// they are reduced over the workgroup once per tile (fixed order: deterministic).
+constexpr int SPB_T = 32, SPB_HALO = SPB_T + 4, SPB_PITCH = SPB_HALO + 1;
 __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __restrict__ g_z,
                                                               const float* __restrict__ pooled,
                                                               const float* __restrict__ w,
                                                               float* __restrict__ g_pooled,
                                                               float* __restrict__ part_w,  // (nblk, 50)
-                                                              int H, int W, long total) {
-  __shared__ float wsh[50];
+                                                              int H, int W, int tiles_x, int tiles_y) {
   __shared__ float red[50][4];
+  __shared__ float tl[3][SPB_HALO][SPB_PITCH];      // g_z, pooled[0], pooled[1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 50) wsh[tid] = w[tid];
-  __syncthreads();
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * SPB_T, y0 = ty * SPB_T;
   const long HW = (long)H * W;
-  float a0[25], a1[25];
+  const float* gz = g_z + (long)b * HW;
+  const float* pl = pooled + (long)b * 2 * HW;
+  for (int e = tid; e < 3 * SPB_HALO * SPB_HALO; e += 256) {
+    const int c = e / (SPB_HALO * SPB_HALO), rem = e - c * (SPB_HALO * SPB_HALO);
+    const int r = rem / SPB_HALO, q = rem - r * SPB_HALO;
+    const int yy = y0 + r - 2, xx = x0 + q - 2;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float* src = c == 0 ? gz : pl + (long)(c - 1) * HW;
+    tl[c][r][q] = in ? src[(long)yy * W + xx] : 0.f;
+  }
+  __syncthreads();
+  // a thread owns 4 consecutive rows of one column: the 8 x 5 window of a plane is read once for its 4 pixels
+  const int cx = tid & 31, r0 = (tid >> 5) * 4;
+  float a0[25], a1[25], win[8][5], gq[4], o0[4], o1[4];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
-#pragma unroll 1
-  for (int k = 0; k < SPB_PPT; ++k) {
-    const long idx = (blockIdx.x * (long)SPB_PPT + k) * 256 + tid;
-    const bool live = idx < total;
-    int gx = 0, gy = 0, b = 0;
-    if (live) {
-      gx = (int)(idx % W);
-      const long t = idx / W;
-      gy = (int)(t % H);
-      b = (int)(t / H);
+  for (int k = 0; k < 4; ++k) gq[k] = tl[0][r0 + k + 2][cx + 2];   // 0 outside the image: its weight-gradient terms vanish
+#define SPB_WINDOW(c_)                                                    \
+  _Pragma("unroll") for (int rr = 0; rr < 8; ++rr)                        \
+    _Pragma("unroll") for (int dx = 0; dx < 5; ++dx) win[rr][dx] = tl[c_][r0 + rr][cx + dx];
+  SPB_WINDOW(1)
+#pragma unroll
+  for (int t = 0; t < 25; ++t) {                   // pooled at q + (dy-2, dx-2)
+    float s_ = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_ = fmaf(gq[k], win[k + t / 5][t % 5], s_);
+    a0[t] = s_;
+  }
+  SPB_WINDOW(2)
+#pragma unroll
+  for (int t = 0; t < 25; ++t) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_ = fmaf(gq[k], win[k + t / 5][t % 5], s_);
+    a1[t] = s_;
+  }
+  SPB_WINDOW(0)
+#undef SPB_WINDOW
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o0[k] = 0.f; o1[k] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {                 // transposed conv: neighbour at q - (dy-2, dx-2); w: scalar loads
+      const float g = win[k + 4 - t / 5][4 - t % 5];
+      o0[k] = fmaf(w[t], g, o0[k]);
+      o1[k] = fmaf(w[25 + t], g, o1[k]);
     }
-    const float* gz = g_z + (long)b * HW;
-    const float* pl = pooled + (long)b * 2 * HW;
-    const float gq = live ? gz[(long)gy * W + gx] : 0.f;
-    float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        // transposed conv: neighbour at q - (dy-2, dx-2)
-        const int yy = gy - (dy - 2), xx = gx - (dx - 2);
-        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-          const float g = gz[(long)yy * W + xx];
-          o0 = fmaf(wsh[dy * 5 + dx], g, o0);
-          o1 = fmaf(wsh[25 + dy * 5 + dx], g, o1);
-        }
-        // weight gradient: pooled at q + (dy-2, dx-2)
-        const int y2 = gy + (dy - 2), x2 = gx + (dx - 2);
-        const bool in2 = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-        a0[dy * 5 + dx] += in2 ? gq * pl[(long)y2 * W + x2] : 0.f;
-        a1[dy * 5 + dx] += in2 ? gq * pl[HW + (long)y2 * W + x2] : 0.f;
-      }
-    }
-    if (live) {
-      g_pooled[(long)b * 2 * HW + (long)gy * W + gx] = o0;
-      g_pooled[(long)b * 2 * HW + HW + (long)gy * W + gx] = o1;
+    const int gy = y0 + r0 + k, gx = x0 + cx;
+    if (gy < H && gx < W) {
+      g_pooled[(long)b * 2 * HW + (long)gy * W + gx] = o0[k];
+      g_pooled[(long)b * 2 * HW + HW + (long)gy * W + gx] = o1[k];
     }
   }
 #pragma unroll
@@ -377,7 +392,7 @@ static const char* basep(const codon_tensor* t, long HW, int dtype) {
 }
 
 int cac_bwd_tiles(int H, int W) { return (int)(((long)H * W + BWD_TILE - 1) / BWD_TILE); }
-int cac_bwd_spatial_blocks(int B, int H, int W) { return (int)(((long)B * H * W + 256 * SPB_PPT - 1) / (256 * SPB_PPT)); }
+int cac_bwd_spatial_blocks(int B, int H, int W) { return B * ((H + SPB_T - 1) / SPB_T) * ((W + SPB_T - 1) / SPB_T); }
 
 int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc,
                    const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
@@ -419,10 +434,9 @@ int cac_bwd_gate(int B, int H, int W, const float* part_gch, const int* part_arg
 
 int cac_bwd_spatial(int B, int H, int W, const float* g_z, const float* pooled, const float* w, float* g_pooled,
                     float* part_w, float* dw, hipStream_t stream) {
-  const long total = (long)B * H * W;
   const int nblk = cac_bwd_spatial_blocks(B, H, W);
   hipLaunchKernelGGL(cac_bwd_spatial_kernel, dim3(nblk), dim3(256), 0, stream, g_z, pooled, w, g_pooled, part_w, H, W,
-                     total);
+                     (W + SPB_T - 1) / SPB_T, (H + SPB_T - 1) / SPB_T);
   int st = check_launch("cac_bwd_spatial_kernel");
   if (st != CODON_OK) return st;
   // two-level fixed-order sum of the (nblk, 50) partials: 64 chunks in place, then the 64 chunk sums
