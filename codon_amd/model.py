@@ -273,10 +273,13 @@ class _CODONBase(nn.Module):
 
         # inference, exact fp32: the gate-apply `out*ad_CAC + inputs` (:89-91,117-118) is formed inside the staging of
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
-        gated = (not keep) and not split5 and (adt == torch.float32 or GATED_16BIT)
+        # 16-bit: with the emitting conv5x5 (GATED_EMIT) the training forward takes the same route -- the emitted tensor IS
+        # the block input the backward needs, bit-identical to cac_apply's output, and the 7.5 GB apply pass is gone there too
+        emit16 = fused_stats and GATED_16BIT and GATED_EMIT and not split5
+        gated = not split5 and (((not keep) and (adt == torch.float32 or GATED_16BIT)) or (keep and emit16))
 
-        emit16 = gated and fused_stats and GATED_EMIT
-        xg = new(128) if emit16 else None      # [out | out_c] as emitted by the gated conv5x5s of a block
+        emit16 = emit16 and gated
+        xg = new(128) if (emit16 and not keep) else None      # [out | out_c] as emitted by the gated conv5x5s of a block
 
         def gconv(gate, pre_s, in_s, plain_s, name, ys, k, emit=None, emitted=None):
             """relu(conv_k(gate-applied input)): `gate` = (ch, sp) of the producing block or None (plain input).
@@ -308,7 +311,7 @@ class _CODONBase(nn.Module):
             pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
             folded = torch.empty((B, L.CAC_FOLDS, 128, 2), **fz)
         cur = in2                       # (B,128): [depth | colour] block input
-        oc = prev_gate = None
+        oc = prev_gate = prev_pre2 = None
         stage = r2 = stage_c = r2_c = pre2 = None
         for i in range(5):
             drop_stage = keep and getattr(self, "recompute", False)
@@ -325,15 +328,19 @@ class _CODONBase(nn.Module):
             out, out_c = Slice(cur, 0, 64), Slice(cur, 64, 64)
             pre, pre_c = Slice(pre2, 0, 64), Slice(pre2, 64, 64)
             gate = prev_gate if (gated and i > 0) else None      # (ch, sp) of block i-1: its apply runs in our staging
+            # ... on block i-1's [pre | pre_c]: the same buffer at inference, the previous block's saved one in training
+            gpre, gpre_c = (Slice(prev_pre2, 0, 64), Slice(prev_pre2, 64, 64)) if gate is not None else (None, None)
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
-            xg_d, xg_c = (Slice(xg, 0, 64), Slice(xg, 64, 64)) if emit16 else (None, None)
-            gconv(gate, pre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
-            gconv(gate, pre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
+            if emit16 and keep and gate is not None:
+                xg = new(128)           # training: the emitted tensor is this block's saved input
+            xg_d, xg_c = (Slice(xg, 0, 64), Slice(xg, 64, 64)) if (emit16 and gate is not None) else (None, None)
+            gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
+            gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
             conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
                       stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
             # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
-            gconv(gate, pre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
-            gconv(gate, pre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
+            gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
+            gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
             conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
                       stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
@@ -348,13 +355,13 @@ class _CODONBase(nn.Module):
                              f32(ac.mlp[3].bias), ch, pools)
             ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
             if gated:
-                prev_gate = (ch, sp)    # consumed by the next block's convs / conv7
+                prev_gate, prev_pre2 = (ch, sp), pre2    # consumed by the next block's convs / conv7
             else:
                 if keep or oc is None:
                     oc = new(128)       # [out | out_c]: also conv7's cat(out, out_c) input  :119
                 ops.cac_apply(pre, pre_c, ch, sp, inputs, inputs_c, Slice(oc, 0, 64), Slice(oc, 64, 64))  # :90-91,117-118
             if keep:
-                save[f"blk{i}"] = dict(x=cur, stage=None if drop_stage else stage, r2=r2,
+                save[f"blk{i}"] = dict(x=xg if (emit16 and gate is not None) else cur, stage=None if drop_stage else stage, r2=r2,
                                        stage_c=None if drop_stage else stage_c, r2_c=r2_c, pre2=pre2,
                                        pooled=pooled, pools=pools, ch=ch, sp=sp)
             if not gated:
@@ -363,7 +370,10 @@ class _CODONBase(nn.Module):
         # fusion trunk                                                               :119-128
         fuse = new(64)
         if gated:
-            ops.conv2d_gated(Slice(pre2), Slice(in2), prev_gate[0], prev_gate[1], P("conv7"), Slice(fuse), 3, relu=True)
+            if keep:
+                cur = new(128)          # [out | out_c] of block 4: conv7's input, emitted for the backward
+            ops.conv2d_gated(Slice(pre2), Slice(in2), prev_gate[0], prev_gate[1], P("conv7"), Slice(fuse), 3, relu=True,
+                             emit=Slice(cur) if keep else None)
         else:
             conv(Slice(cur), "conv7", Slice(fuse), 3, relu=True)
         if keep:

@@ -321,3 +321,33 @@ def test_inference_schedules_agree_bit_for_bit(dtype):
         M.GATED_16BIT, M.GATED_EMIT = old
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_training_schedules_agree_bit_for_bit():
+    """bf16 training forward: cac_apply pass vs gated + emitting convs (the emitted tensors are the saved block inputs):
+    same output, same gradients, bit for bit."""
+    import codon_amd
+    from codon_amd import model as M
+    dev = _dev()
+    torch.manual_seed(5)
+    net = codon_amd.CODONNet().to(dev)
+    net.set_compute_dtype(torch.bfloat16)
+    net.train()
+    x = torch.rand((2, 1, 37, 70), device=dev)
+    y = torch.rand((2, 1, 37, 70), device=dev)
+    gy = torch.randn((2, 1, 37, 70), device=dev)
+    res = []
+    old = M.GATED_EMIT
+    try:
+        for emit in (True, False):
+            M.GATED_EMIT = emit
+            net.zero_grad(set_to_none=True)
+            out = net(x, y)
+            out.backward(gy)
+            res.append((out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        M.GATED_EMIT = old
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 40
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
