@@ -53,6 +53,7 @@ SIGNATURES = {
     "codon_conv2d_gated_emit_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _TP, _P, _P, _P, _P, _TP, _P]),
     "codon_conv_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "codon_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _I, _P]),
+    "codon_conv1x1_bwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _TP, _P, _P, C.c_size_t, _I, _P]),
     "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_cac_stats_tiles": (_I, [_I, _I]),

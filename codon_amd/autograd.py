@@ -6,7 +6,7 @@ CODON_x4.py:66-132.  Here forward keeps every activation the backward needs (cod
   * dL/dx of every MFMA conv = the forward conv kernel on PACK_DGRAD weights, with the ReLU mask of the
     tensor the gradient flows INTO fused in the epilogue (MASK_RELU) and fan-in fused as ACCUM_OUT;
   * dL/dw = codon_conv2d_wgrad, accumulating across the 5 / 3 loop iterations that share weights
-    (CODON_x4.py:74,122);
+    (CODON_x4.py:74,122); 16-bit: the 1x1 convs' dL/dw and masked dL/dx come from one pass (codon_conv1x1_bwd);
   * CAC gate backward = ops.cac_backward (4 kernels);
   * stem / head: stencil + 1-channel wgrad.
 Gradients w.r.t. the two input images are not produced (the reference never asks for them).
@@ -15,9 +15,14 @@ from __future__ import annotations
 
 import torch
 
+import os as _os
+
 from . import _lib as L
 from . import ops
 from .ops import Slice
+
+# 16-bit: dL/dw and dL/dx of the three 128 -> 64 1x1 convs in one pass each (codon_conv1x1_bwd); 0 = two kernels (A/B)
+FUSED_1X1_BWD = _os.environ.get("CODON_FUSED_1X1_BWD", "1") != "0"
 
 # parameters in a fixed order: the flat gradient buffer of codon_amd.dist uses the same order
 _CONVS = ["input", "conv_input", "conv1", "conv2", "conv3", "confuse", "input_c", "conv_input_c", "conv4", "conv5",
@@ -88,6 +93,21 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(xs, model._packed(second[0]), Slice(buf, 64, 64), second[1], relu=True)
         return buf
 
+    fused1 = ops.is_c8(adt) and FUSED_1X1_BWD
+
+    def bwd1x1(name, xs: Slice, gs: Slice, gxs: Slice):
+        """both gradients of a 1x1 conv on a ReLU output xs: dW (accumulated over the shared uses) and gx = (W^T g) * [xs > 0];
+        16-bit: one pass over xs and gs (codon_conv1x1_bwd), else the wgrad + the masked dgrad conv."""
+        if not fused1:
+            wgrad(name, xs, gs, 1)
+            ops.conv2d(gs, Pd(name), gxs, 1, relu_mask=xs)
+            return
+        key = name + ".weight"
+        first = key not in G
+        if first:
+            G[key] = torch.empty_like(getattr(model, name).weight, dtype=torch.float32)
+        ops.conv1x1_bwd(xs, gs, Pd(name), gxs, G[key], accumulate=not first)
+
     def wgrad(name, xs: Slice, gs: Slice, k: int):
         key = name + ".weight"
         if key in G:
@@ -119,8 +139,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             g_fuse = g_f.clone()
         else:
             ops.ew_add_mask(Slice(g_fuse), Slice(g_f))
-        wgrad("confuse_fuse", Slice(r2), Slice(g_f), 1)
-        ops.conv2d(Slice(g_f), Pd("confuse_fuse"), Slice(g_r2), 1, relu_mask=Slice(r2))
+        bwd1x1("confuse_fuse", Slice(r2), Slice(g_f), Slice(g_r2))
         wgrad("conv10", Slice(stage), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv10"), Slice(g_stage), 5, relu_mask=Slice(stage))
         wgrad("conv8", Slice(xin), Slice(g_stage, 0, 64), 5)
@@ -163,8 +182,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             g_x, acc0 = g_in2, True
         # depth stream: pre = confuse(r2); r2 = relu(conv3(stage)); stage = [relu(conv1(x)) | relu(conv2(x))]
         stage = restage(Bk["stage"], Slice(xin, 0, 64), ("conv1", 3), ("conv2", 5))
-        wgrad("confuse", Slice(r2), Slice(g_pre2, 0, 64), 1)
-        ops.conv2d(Slice(g_pre2, 0, 64), Pd("confuse"), Slice(g_r2), 1, relu_mask=Slice(r2))
+        bwd1x1("confuse", Slice(r2), Slice(g_pre2, 0, 64), Slice(g_r2))
         wgrad("conv3", Slice(stage), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv3"), Slice(g_stage), 5, relu_mask=Slice(stage))
         wgrad("conv1", Slice(xin, 0, 64), Slice(g_stage, 0, 64), 3)
@@ -173,8 +191,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True)
         # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
         stage_c = restage(Bk["stage_c"], Slice(xin, 64, 64), ("conv4", 5), ("conv5", 3))
-        wgrad("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), 1)
-        ops.conv2d(Slice(g_pre2, 64, 64), Pd("confuse_c"), Slice(g_r2), 1, relu_mask=Slice(r2_c))
+        bwd1x1("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), Slice(g_r2))
         wgrad("conv6", Slice(stage_c), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv6"), Slice(g_stage), 5, relu_mask=Slice(stage_c))
         wgrad("conv4", Slice(xin, 64, 64), Slice(g_stage, 0, 64), 5)

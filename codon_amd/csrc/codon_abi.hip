@@ -45,6 +45,8 @@ int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*
                          const codon_tensor*, float*, float*, int, hipStream_t);
 int conv2d_gated_fwd_16(const codon_conv_desc*, const void*, const codon_tensor*, const float*, const float*, const void*,
                         void*, const codon_tensor*, hipStream_t);
+int conv1x1_bwd_16(const codon_conv_desc*, const void*, const void*, const void*, const codon_tensor*, float*, float*, size_t,
+                   int, hipStream_t);
 int cac_fused_tiles(int, int);
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -297,6 +299,21 @@ int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, 
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_wgrad: dtype %d", d->dtype);
   return conv2d_wgrad_f32(d, (const float*)x, (const float*)gy, dw, (float*)workspace, workspace_bytes, accumulate,
                           (hipStream_t)stream);
+}
+
+int codon_conv1x1_bwd(const codon_conv_desc* d, const void* x, const void* gy, const void* w_packed_dgrad,
+                      const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
+                      codon_stream_t stream) {
+  CODON_REQUIRE(d && x && gy && w_packed_dgrad && gx && gx->data && dw && workspace, CODON_ERR_BAD_ARG,
+                "conv1x1_bwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv1x1_bwd: bad shape");
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
+                    d->y_coff + d->cout <= d->y_ctotal && gx->coff >= 0 && gx->coff + d->cin <= gx->ctotal,
+                CODON_ERR_BAD_ARG, "conv1x1_bwd: channel slice outside its buffer");
+  CODON_REQUIRE(((uintptr_t)w_packed_dgrad % 16) == 0, CODON_ERR_BAD_ARG, "conv1x1_bwd: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "conv1x1_bwd: 16-bit dtypes only (dtype %d): call codon_conv2d_wgrad + codon_conv2d_fwd", d->dtype);
+  return conv1x1_bwd_16(d, x, gy, w_packed_dgrad, gx, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream);
 }
 
 int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_oihw, void* y,

@@ -83,10 +83,16 @@ struct WgradC8Params {
   int H, W, cin, cout;
   long x_img, g_img, x_base, g_base;   // 16-byte vectors
   int tiles_x, nbands, nsplit;
+  // k = 1, DG: the same pass also produces the conv's input gradient  gx = (W^T gy) * [x > 0]   (x = relu(...) is the
+  // 1x1 conv's input: its own ReLU mask) from the tiles it has in LDS anyway
+  const uint4* dg_w;                   // CODON_PACK_DGRAD image of the (64,128,1,1) weight: [ks][h][128 rows][8]
+  uint4* dg_y;
+  long dy_img, dy_base;
 };
 
-template <class E, int KS>
+template <class E, int KS, bool DG = false>
 __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
+  static_assert(!DG || KS == 1, "the fused input gradient exists for the 1x1 conv only");
   typedef typename E::vec8 vec8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr bool KSPLIT = (KS == 1);
@@ -355,6 +361,21 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
       run(std::false_type{});
     }
   } else {
+  // DG: this wave's A operands (rows = the 64 input channels 64 co_t .. +63 of the 1x1 conv, K = its 64 output channels)
+  // stay in registers for the whole band; gx goes out through a descriptor on the image
+  vec8 wa[DG ? 2 : 1][DG ? 4 : 1];
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(DG ? p.dg_y + b * p.dy_img + p.dy_base : (uint4*)p.ws), 0, (int)(16u * HW16), C8_RSRC_FLAGS);
+  if constexpr (DG) {
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.dg_w, 0, 64 * 128 * 2, C8_RSRC_FLAGS);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 v = c8_ld(wr_, (unsigned)((half * 128 + (2 * co_t + t2) * 32 + l31) * 16), (unsigned)(ks * 2 * 128 * 16));
+        wa[t2][ks] = *reinterpret_cast<const vec8*>(&v);
+      }
+  }
   if (ntile > 0) {
     load_tile(0);
     store_tile(0);
@@ -400,6 +421,37 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
           ub.s.l = wk[j][0]; ub.s.h = wk[j][1];
           acc[j] = E::mfma(ua.v, ub.v, acc[j]);
         }
+      }
+      if constexpr (DG) {
+        // input gradient of tile row `krow`, channel tiles 2 co_t, 2 co_t + 1: B fragment of k-step ks = the 16-byte
+        // vector of gy plane 2 ks + h at the lane's pixel (the LDS tile keeps the HBM form), 8 MFMAs; rows come out as
+        // 8 consecutive channels per (tile, g) (swap23 packing), masked by x from the same LDS tile, one 16-byte store
+        const int pix = krow * TW + l31;
+        f32x16 d[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[t2][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 bv = *reinterpret_cast<const u32x4*>(gs + (2 * ks + half) * GPITCH + pix * 16);
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) d[t2] = E::mfma(wa[t2][ks], *reinterpret_cast<const vec8*>(&bv), d[t2]);
+        }
+        const int gy_ = (ty_begin + t / p.tiles_x) * TH + krow, gx_ = (t % p.tiles_x) * TW + l31;
+        const unsigned vo = (gy_ < H && gx_ < W) ? (unsigned)half * HW16 + 16u * (unsigned)(gy_ * W + gx_) : C8_OOB;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int plane0 = (2 * co_t + t2) * 4 + 2 * g, plane = plane0 + half;     // plane0: wave-uniform
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(xs + plane * XPITCH + pix * 16);
+            float r8[8], v8[8];
+            c8_unpack<E>(rv, r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = r8[j] > 0.f ? d[t2][8 * g + j] : 0.f;
+            c8_st(c8_pack<E>(v8), dyr, vo, (unsigned)plane0 * HW16);
+          }
       }
     } else {
       WC8_READ(0, 0)
@@ -526,6 +578,7 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   p.x_base = (d->x_coff / 8) * HW; p.g_base = (d->y_coff / 8) * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.nbands = pl.nbands; p.nsplit = pl.nsplit;
+  p.dg_w = nullptr; p.dg_y = nullptr; p.dy_img = p.dy_base = 0;
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
   const bool f16 = d->dtype == CODON_F16;
   if (d->ksize == 5) {
@@ -541,6 +594,39 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   const int st = check_launch("conv_wgrad_c8_kernel");
   if (st != CODON_OK) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
+}
+
+// dL/dw AND dL/dx of a 1x1 conv 128 -> 64 whose input is a ReLU output (confuse / confuse_c / confuse_fuse,
+// CODON_x4.py:84,83,127), one pass: both are HBM-bound on the same two tensors (x = r2 128 ch, gy 64 ch)
+int conv1x1_bwd_16(const codon_conv_desc* d, const void* x, const void* gy, const void* w_dgrad, const codon_tensor* gx,
+                   float* dw, float* workspace, size_t ws_bytes, int accumulate, hipStream_t stream) {
+  Wgrad16Plan pl;
+  CODON_REQUIRE(d->ksize == 1 && d->cin == 128 && d->cout == 64 && wgrad16_plan(d, &pl), CODON_ERR_UNSUPPORTED,
+                "conv1x1_bwd: k=%d cin=%d cout=%d (the fused pass exists for the 128 -> 64 1x1 convs)", d->ksize, d->cin, d->cout);
+  CODON_REQUIRE(c8_slice_ok(d->x_ctotal, d->x_coff, d->cin) && c8_slice_ok(d->y_ctotal, d->y_coff, d->cout) &&
+                    c8_slice_ok(gx->ctotal, gx->coff, d->cin),
+                CODON_ERR_BAD_ARG, "conv1x1_bwd: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
+  CODON_REQUIRE(ws_bytes >= conv_wgrad_bf16_workspace_bytes(d), CODON_ERR_BAD_ARG,
+                "conv1x1_bwd: workspace %zu B < required %zu B", ws_bytes, conv_wgrad_bf16_workspace_bytes(d));
+  CODON_REQUIRE(pl.nsplit <= 65535, CODON_ERR_UNSUPPORTED, "conv1x1_bwd: %d splits > 65535", pl.nsplit);
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv1x1_bwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  WgradC8Params p;
+  p.x = (const uint4*)x; p.gy = (const uint4*)gy; p.ws = workspace;
+  p.H = d->height; p.W = d->width; p.cin = d->cin; p.cout = d->cout;
+  p.x_img = (d->x_ctotal / 8) * HW; p.g_img = (d->y_ctotal / 8) * HW;
+  p.x_base = (d->x_coff / 8) * HW; p.g_base = (d->y_coff / 8) * HW;
+  p.tiles_x = (d->width + 31) / 32;
+  p.nbands = pl.nbands; p.nsplit = pl.nsplit;
+  p.dg_w = (const uint4*)w_dgrad; p.dg_y = (uint4*)gx->data;
+  p.dy_img = (gx->ctotal / 8) * HW; p.dy_base = (gx->coff / 8) * HW;
+  const dim3 grid(pl.nchan_blocks, pl.nsplit);
+  if (d->dtype == CODON_F16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  const int st = check_launch("conv_wgrad_c8_kernel<1, dgrad>");
+  if (st != CODON_OK) return st;
+  return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, 1, pl.nsplit, accumulate, stream);
 }
 
 }  // namespace codon

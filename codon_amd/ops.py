@@ -253,6 +253,24 @@ def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: 
             prof["wgrad_events"].append((e0, e1))
 
 
+def conv1x1_bwd(x: Slice, gy: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: torch.Tensor, accumulate: bool = False):
+    """16-bit, 1x1 conv 128 -> 64 on a ReLU output x: dw (+)= dL/dw and gx = (W^T gy) * [x > 0] in one pass over x, gy."""
+    lib = L.load()
+    dev = _dev(x.buf, gy.buf, w_packed_dgrad, gx.buf, dw)
+    B, H, W = _bhw(x.buf)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, 1, 1) and gx.c == x.c and _bhw(gx.buf) == (B, H, W)
+    assert gx.buf.dtype == x.buf.dtype == gy.buf.dtype and gx.buf.data_ptr() not in (x.buf.data_ptr(), gy.buf.data_ptr())
+    d = L.ConvDesc(B, H, W, x.c, gy.c, 1, x.ctotal, x.coff, gy.ctotal, gy.coff, 0, 0, 0, _dt(x.buf))
+    nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(f"codon_amd: no wgrad kernel for k=1 cin={x.c} cout={gy.c}")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    gt = gx.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_conv1x1_bwd(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(w_packed_dgrad), C.byref(gt), _ptr(dw),
+                                      _ptr(ws), nbytes, 1 if accumulate else 0, _stream(dev)), "conv1x1_bwd")
+
+
 def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
     lib = L.load()
     dev = _dev(x, w, y.buf)

@@ -166,6 +166,16 @@ size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d);
 int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, float* dw,
                        void* workspace, size_t workspace_bytes, int32_t accumulate,
                        codon_stream_t stream);
+/* Both gradients of a 1x1 conv 128 -> 64 whose input is a ReLU output, in ONE pass over x and gy (16-bit dtypes):
+ *   dw (+)= dL/dw as codon_conv2d_wgrad;   gx = (W^T gy) * [x > 0]   as codon_conv2d_fwd on the CODON_PACK_DGRAD image with
+ *   CODON_CONV_MASK_RELU and x as the mask -- bit for bit the results of those two calls.
+ * confuse / confuse_c / confuse_fuse and the ReLU in front of them: /root/reference/CODON_X4/CODON_x4.py:81-84,126-127
+ * (autograd; the reference has no explicit backward).  d describes the FORWARD conv (k = 1, cin = 128,
+ * cout = 64; x_* = its input, y_* = gy's buffer), gx = the (B,128,H,W) slice the input gradient is written to (must
+ * not alias x or gy), workspace as codon_conv_wgrad_workspace_bytes(d). */
+int codon_conv1x1_bwd(const codon_conv_desc* d, const void* x, const void* gy, const void* w_packed_dgrad,
+                      const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
+                      codon_stream_t stream);
 
 /* ---- stem / head stencils (HBM-bound) ----------------------------------------------------
  * stem: y[:, y_coff:y_coff+64] = relu(conv3x3_{1->64}(x))        CODON_x4.py:68,71

@@ -351,3 +351,47 @@ def test_training_schedules_agree_bit_for_bit():
     assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 40
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+    # ... and so do the fused / two-kernel backward of the 1x1 convs
+    from codon_amd import autograd as A
+    oldf = A.FUSED_1X1_BWD
+    try:
+        A.FUSED_1X1_BWD = not oldf
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g2 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.FUSED_1X1_BWD = oldf
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], g2[n]), n
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 33, 70), (2, 64, 96)])
+def test_conv1x1_bwd_equals_wgrad_plus_masked_dgrad(shape, dtype):
+    """codon_conv1x1_bwd (dW and the ReLU-masked dX of a 128 -> 64 1x1 conv from one pass over x and gy) == codon_conv2d_wgrad
+    + codon_conv2d_fwd(PACK_DGRAD, MASK_RELU), bit for bit, including accumulation into dW and slices of wider buffers."""
+    from codon_amd import ops
+    from codon_amd import _lib as L
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = ops.from_nchw(torch.relu(_rand((B, 192, H, W), 1)).to(dev), dtype)       # the conv input = channels 64..191
+    g = ops.from_nchw(_rand((B, 128, H, W), 2).to(dev), dtype)                  # gy = channels 64..127
+    w = _rand((64, 128, 1, 1), 3, 0.1).to(dev)
+    wp = ops.packed_weight(w, mode=L.PACK_DGRAD, dtype=dtype)
+    xs, gs = Slice(x, 64, 128), Slice(g, 64, 64)
+    dw0 = torch.full((64, 128, 1, 1), 0.5, device=dev)
+    dw1 = dw0.clone()
+    gx0 = ops.new_act(B, 128, H, W, dtype, dev)
+    gx1 = ops.new_act(B, 256, H, W, dtype, dev).fill_(float("nan"))
+    for acc in (False, True):
+        ops.conv2d_wgrad(xs, gs, dw0, 1, accumulate=acc)
+        ops.conv2d(gs, wp, Slice(gx0), 1, relu_mask=xs)
+        ops.conv1x1_bwd(xs, gs, wp, Slice(gx1, 64, 128), dw1, accumulate=acc)
+        assert torch.equal(dw0, dw1)
+        got = ops.to_nchw(gx1)
+        assert torch.equal(got[:, 64:192], ops.to_nchw(gx0))
+        assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 192:]).all()
+    ref = torch.einsum("bohw,oi->bihw", ops.to_nchw(g)[:, 64:].float(), w[:, :, 0, 0]) * (ops.to_nchw(x)[:, 64:] > 0)
+    assert rel_rmse(ops.to_nchw(gx0).float().cpu(), ref.cpu()) < _tol(dtype)
