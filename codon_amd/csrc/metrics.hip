@@ -213,11 +213,22 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[0] = sum_i partial[i] in double, fixed order (single thread: a few thousand terms)
-__global__ void sum_partials_f64_kernel(const float* __restrict__ partial, int n, double scale, double* __restrict__ out) {
+// out[0] = sum_i partial[i] in double, fixed order: 256 contiguous chunks summed in parallel, then the 256 chunk sums in
+// index order (one thread walking ~10^4 dependent loads took 0.43 ms of a training step)
+__global__ __launch_bounds__(256) void sum_partials_f64_kernel(const float* __restrict__ partial, int n, double scale,
+                                                              double* __restrict__ out) {
+  __shared__ double red[256];
+  const int per = (n + 255) / 256;
+  const int i0 = threadIdx.x * per, i1 = min(i0 + per, n);
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)partial[i];
-  out[0] = s * scale;
+  for (int i = i0; i < i1; ++i) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 256; ++k) t += red[k];
+    out[0] = t * scale;
+  }
 }
 
 static GaussW make_gauss(double sd) {
@@ -259,7 +270,7 @@ int ssim_fwd(int B, int H, int W, const float* a, const float* b, float* partial
                      0.01f * 0.01f, 0.03f * 0.03f);
   int st = check_launch("ssim_fwd_kernel");
   if (st != CODON_OK) return st;
-  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(1), 0, stream, partial, nt, 1.0 / ((double)B * H * W),
+  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(256), 0, stream, partial, nt, 1.0 / ((double)B * H * W),
                      value);
   return check_launch("sum_partials_f64_kernel");
 }
@@ -268,7 +279,7 @@ int l1_fwd(long n, const float* a, const float* b, float* partial, int nparts, d
   hipLaunchKernelGGL(l1_partial_kernel, dim3(nparts), dim3(256), 0, stream, a, b, partial, n);
   int st = check_launch("l1_partial_kernel");
   if (st != CODON_OK) return st;
-  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(1), 0, stream, partial, nparts, 1.0 / (double)n, value);
+  hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(256), 0, stream, partial, nparts, 1.0 / (double)n, value);
   return check_launch("sum_partials_f64_kernel");
 }
 
