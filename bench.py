@@ -274,7 +274,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_c8_kernel<5>" if dtype == "bf16" else "conv_wgrad_f32_t16_kernel<5>") +
                                    " 128->128 + its fixed-order reduce (dW of conv3 / conv6 / conv10)",
                          "achieved": wach, "peak": peak, "unit": "TFLOP/s", "frac": wach / peak,
-                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5>", B, H, W,
+                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5", B, H, W,
                                                 "r*_bf16_train_b32_480x640_pmc.json") if dtype == "bf16" else None,
                          "traffic_note": "PMC average over the 5x5 wgrad launches of a step (128->128 and 64->64 shapes share the kernel)",
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
