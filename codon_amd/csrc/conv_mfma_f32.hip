@@ -495,6 +495,31 @@ static bool small_grid(const codon_conv_desc* d) {
   return (long)((d->width + 31) / 32) * ((d->height + 7) / 8) * d->batch < SMALL_GRID;
 }
 
+// Small grids leave CUs empty, and the host runs the two streams of a block on two HIP streams (model.py) -- but the
+// dispatcher puts the workgroups of two concurrent 128-workgroup launches on the SAME CUs (rocprofv3 trace: both overlap in
+// time and each takes 345 us instead of 202).  A dynamic-LDS request that brings a workgroup above half of the CU's 160 KB
+// makes every workgroup the only one on its CU, so a concurrent launch must take the free CUs.  Bytes of padding for `kernel`.
+#ifndef CODON_SOLO_LDS
+#define CODON_SOLO_LDS 1
+#endif
+template <class K>
+static unsigned solo_lds_pad(K kernel) {
+  static int pad = -1;                    // one per kernel instantiation; a racing first call computes the same value
+  if (pad < 0) {
+    int want = 0;
+    hipFuncAttributes a;
+    if (CODON_SOLO_LDS && hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess) {
+      want = 82 * 1024 - (int)a.sharedSizeBytes;
+      if (want < 0) want = 0;
+      if (want > 0 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+        want = 0;
+    }
+    (void)hipGetLastError();
+    pad = want;
+  }
+  return (unsigned)pad;
+}
+
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* w, float* y,
                          const float* res, hipStream_t stream) {
@@ -518,7 +543,8 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
 #endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  const unsigned dyn = (PSEG == 1 && small_grid(d)) ? solo_lds_pad(conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>) : 0u;
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), dyn, stream, p);
   return check_launch("conv_mfma_f32_kernel");
 }
 
@@ -555,7 +581,8 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  const unsigned dyn = (PSEG == 1 && small_grid(d)) ? solo_lds_pad(conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>) : 0u;
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>), dim3((unsigned)nblk), dim3(256), dyn, stream, p);
   return check_launch("conv_mfma_f32_kernel<gated>");
 }
 
@@ -610,7 +637,8 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   p.dbg = codon_dbg_ptr();
 #endif
   if (small)
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64),
+                       solo_lds_pad(conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), stream, p);
   else
     hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");

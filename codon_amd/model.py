@@ -30,6 +30,22 @@ GATED_16BIT = _os.environ.get("CODON_GATED16", "1") != "0"
 # 16-bit gated inference: the conv5x5 of a sibling pair applies the gate and EMITS the gated tensor, the conv3x3 reads it as
 # a plain conv (its staging is bound by the gate arithmetic otherwise: 1.00 vs 0.71 ms at 32x480x640).  0 = both gated (A/B)
 GATED_EMIT = _os.environ.get("CODON_GATED_EMIT", "1") != "0"
+# inference on a grid too small to fill the chip (every conv launch < 256 workgroups: one 128 x 128 image is 128): the depth
+# and the colour stream of a block are independent up to the CAC gate -- run them on two HIP streams.  0 = one stream (A/B)
+TWO_STREAMS = _os.environ.get("CODON_TWO_STREAMS", "1") != "0"
+_HALF_STREAMS: Dict[int, tuple] = {}
+
+
+def _half_chip_streams(dev):
+    """Two side streams for the two halves of a block.  (Streams created with hipExtStreamCreateWithCUMask were tried to keep
+    the two launches on disjoint CUs: 6.0 ms instead of 4.4 with ANY mask, also the full one -- the external streams'
+    event traffic; what separates the launches instead is the LDS request of the small-grid kernels, conv_mfma_f32.hip.)"""
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    if i not in _HALF_STREAMS:
+        _HALF_STREAMS[i] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _HALF_STREAMS[i]
+
+
 # debug: re-pack on every cache hit and compare, so a write through `.data` after the first forward (the reference's own
 # init idiom is m.weight.data.normal_(), CODON_x4.py:50-53) raises instead of silently using stale packed weights
 VERIFY_PACKED = _os.environ.get("CODON_VERIFY_PACKED", "0") != "0"
@@ -305,6 +321,29 @@ class _CODONBase(nn.Module):
         if keep:
             save["stem"], save["stem_c"], save["in2"] = t64, t64c, in2
 
+        # small grids (inference): two HIP streams, fork before the streams of a block, join at its gate
+        two = TWO_STREAMS and (not keep) and dev.type == "cuda" and B * ((H + 3) // 4) * ((W + 31) // 32) <= 256
+        main_s = torch.cuda.current_stream(dev) if two else None
+        halves = _half_chip_streams(dev) if two else None
+
+        class _on_half:
+            """`with _on_half(k):` runs the body on half-chip stream k, ordered after everything issued so far on the main one."""
+            def __init__(self_, k):
+                self_.k = k
+            def __enter__(self_):
+                if two:
+                    halves[self_.k].wait_stream(main_s)
+                    self_.ctx = torch.cuda.stream(halves[self_.k])
+                    self_.ctx.__enter__()
+            def __exit__(self_, *a):
+                if two:
+                    self_.ctx.__exit__(*a)
+
+        def join():
+            if two:
+                main_s.wait_stream(halves[0])
+                main_s.wait_stream(halves[1])
+
         nt = ops.cac_fused_tiles(H, W) if fused_stats else ops.cac_stats_tiles(H, W)
         fz = dict(dtype=torch.float32, device=dev)
         if fused_stats:
@@ -318,8 +357,8 @@ class _CODONBase(nn.Module):
             if keep or stage is None:
                 stage = stage if (drop_stage and stage is not None) else new(128)
                 r2, pre2 = new(128), new(128)
-                stage_c = (stage_c if (drop_stage and stage_c is not None) else new(128)) if keep else stage
-                r2_c = new(128) if keep else r2
+                stage_c = (stage_c if (drop_stage and stage_c is not None) else new(128)) if keep else (new(128) if two else stage)
+                r2_c = new(128) if (keep or two) else r2
                 pooled = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
                 partials = torch.empty((B, nt, 128, 2), dtype=torch.float32, device=dev)
                 sp = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
@@ -330,19 +369,22 @@ class _CODONBase(nn.Module):
             gate = prev_gate if (gated and i > 0) else None      # (ch, sp) of block i-1: its apply runs in our staging
             # ... on block i-1's [pre | pre_c]: the same buffer at inference, the previous block's saved one in training
             gpre, gpre_c = (Slice(prev_pre2, 0, 64), Slice(prev_pre2, 64, 64)) if gate is not None else (None, None)
-            # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
+            # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80   (side stream on small grids)
             if emit16 and keep and gate is not None:
                 xg = new(128)           # training: the emitted tensor is this block's saved input
             xg_d, xg_c = (Slice(xg, 0, 64), Slice(xg, 64, 64)) if (emit16 and gate is not None) else (None, None)
-            gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
-            gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
-            conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
-                      stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
-            # colour stream: stage_c = [conv4 5x5 | conv5 3x3]                       :76,78,80
-            gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
-            gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
-            conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
-                      stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
+            with _on_half(1):
+                gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
+                gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
+                conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
+                          stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
+            # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
+            with _on_half(0):
+                gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
+                gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
+                conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
+                          stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
+            join()
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
             ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
             if fused_stats:
@@ -385,8 +427,11 @@ class _CODONBase(nn.Module):
             if keep:
                 stage = stage if (drop_stage and stage is not None) else new(128)
                 r2, fA = new(128), new(64)
-            conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
-            conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
+            with _on_half(1):
+                conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
+            with _on_half(0):
+                conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
+            join()
             conv5_1x1(Slice(stage), "conv10", "confuse_fuse", Slice(r2), Slice(fA), residual=Slice(fuse))  # :126-128
             if keep:
                 save[f"trunk{i}"] = dict(x=f, stage=None if drop_stage else stage, r2=r2)

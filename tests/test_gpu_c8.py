@@ -395,3 +395,37 @@ def test_conv1x1_bwd_equals_wgrad_plus_masked_dgrad(shape, dtype):
         assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 192:]).all()
     ref = torch.einsum("bohw,oi->bihw", ops.to_nchw(g)[:, 64:].float(), w[:, :, 0, 0]) * (ops.to_nchw(x)[:, 64:] > 0)
     assert rel_rmse(ops.to_nchw(gx0).float().cpu(), ref.cpu()) < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_stream_schedule_is_bit_identical(dtype):
+    """Small grids (one 128 x 128 image: BASELINE configs[0]) run the depth and the colour stream of a block on two HIP
+    streams; same kernels, same operands: the output must not change, eager and under hipGraph capture."""
+    import codon_amd
+    from codon_amd import model as M
+    dev = _dev()
+    torch.manual_seed(7)
+    net = codon_amd.CODONNet().to(dev).eval()
+    if dtype != torch.float32:
+        net.set_compute_dtype(dtype)
+    x = torch.rand((1, 1, 128, 128), device=dev)
+    y = torch.rand((1, 1, 128, 128), device=dev)
+    old = M.TWO_STREAMS
+    outs = []
+    try:
+        for two in (True, False):
+            M.TWO_STREAMS = two
+            with torch.no_grad():
+                for _ in range(3):                       # repeated: a missing join would show as a race
+                    outs.append(net(x, y).clone())
+        M.TWO_STREAMS = True
+        from codon_amd.graph import GraphedCODON
+        g = GraphedCODON(net, x, y)
+        outs.append(g(x, y).clone())
+        outs.append(g(x, y).clone())
+    finally:
+        M.TWO_STREAMS = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)

@@ -14,3 +14,12 @@ with torch.no_grad():
         m(x, y)
     torch.cuda.synchronize()
 print(f"1x128x128 fp32: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/forward")
+from codon_amd.graph import GraphedCODON
+g = GraphedCODON(m, x, y)
+for _ in range(3):
+    g(x, y)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50):
+    g(x, y)
+torch.cuda.synchronize()
+print(f"1x128x128 fp32, hipGraph replay: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms/forward")
