@@ -83,12 +83,15 @@ enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
 #ifndef CODON_C8_NW564
 #define CODON_C8_NW564 4
 #endif
+#ifndef CODON_C8_NW364
+#define CODON_C8_NW364 4
+#endif
 #ifndef CODON_C8_DMA
 #define CODON_C8_DMA 1     // stage x and weights by LDS-DMA (buffer_load_dwordx4 ... lds); 0: through registers (A/B)
 #endif
 template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_C8_PSEG3 : 2; };
 // waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
-template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : 4; };
+template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : (KS == 3 && COUT == 64) ? CODON_C8_NW364 : 4; };
 
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
