@@ -1,4 +1,5 @@
-# timing ablations of conv_c8_kernel<3,64,64> (variants built with tools/ab_build.sh c<mask> conv_c8.hip -DABL=<mask>)
+# timing ablations of conv_c8_kernel<3,64,64>: apply tools/probes/conv3_ablation.patch, build variants with
+#   tools/ab_build.sh c<mask> conv_c8.hip -DABL=<mask>, revert the patch, then run this on the GPU box
 mkdir -p gpurun_out/abl; rm -f gpurun_out/abl/c3.txt
 for rep in 1 2; do
 for a in base "$@"; do

@@ -1,4 +1,5 @@
-# timing ablations of conv_wgrad_c8_kernel<5> (variants built with tools/ab_build.sh <tag> conv_wgrad_c8.hip -D...): 5x5 128->128 and 64->64
+# timing ablations of conv_wgrad_c8_kernel<5>: apply tools/probes/wgrad_ablation.patch, build variants with
+#   tools/ab_build.sh n<mask> conv_wgrad_c8.hip -DABL=<mask>, revert the patch, then run this on the GPU box
 mkdir -p gpurun_out/abl
 rm -f gpurun_out/abl/out.txt
 for a in base "$@"; do
