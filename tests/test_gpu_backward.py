@@ -392,3 +392,32 @@ def test_packed_weight_verification_catches_data_writes(monkeypatch):
             m(x, x)
         m.invalidate_packed()
         assert not torch.equal(m(x, x), o0)
+
+
+@pytest.mark.gpu
+def test_full_size_training_step_is_deterministic():
+    """16 x 480 x 640 bf16, forward + backward three times on the same inputs: output and every parameter gradient are
+    bit-identical between runs.  All reductions are fixed-order; what this guards is the hand-synchronised code -- LDS-DMA
+    tiles read through inline-asm transposing reads with counted `s_waitcnt lgkmcnt`, the barrier placed ahead of a tile's
+    last k-step (conv_wgrad_c8.hip), the emitting gated convs, the fused 1x1 backward: a race there is a mismatch here."""
+    import codon_amd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = codon_amd.CODONNet().to(dev)
+    net.set_compute_dtype(torch.bfloat16)
+    net.train()
+    B, H, W = 16, 480, 640
+    x, y = torch.rand((B, 1, H, W), device=dev), torch.rand((B, 1, H, W), device=dev)
+    gy = torch.randn((B, 1, H, W), device=dev)
+    ref = None
+    for _ in range(3):
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        g["__out__"] = out.detach().clone()
+        if ref is None:
+            ref = g
+            assert all(torch.isfinite(v).all() for v in g.values())
+        else:
+            assert [n for n in ref if not torch.equal(ref[n], g[n])] == []
