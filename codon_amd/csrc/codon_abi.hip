@@ -36,7 +36,7 @@ int conv2d_wgrad_bf16(const codon_conv_desc*, const void*, const void*, float*, 
 int pack_weight_f32(const float*, float*, int, int, int, int, hipStream_t);
 int pack_chain1x1_f32(const float*, float*, hipStream_t);
 int conv2d_gated_fwd_f32(const codon_conv_desc*, const float*, const codon_tensor*, const float*, const float*, const float*,
-                         float*, hipStream_t);
+                         float*, const codon_tensor*, hipStream_t);
 int pack_chain1x1_16(const float*, void*, int, hipStream_t);
 int pack_chain1x1_f32x3(const float*, void*, hipStream_t);
 int conv_chain1x1_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const void*, const codon_tensor*,
@@ -264,9 +264,9 @@ static int gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tens
   if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
     return conv2d_gated_fwd_16(d, pre, inputs, ch, sp, w_packed, y, gated_out, (hipStream_t)stream);
   CODON_REQUIRE(d->dtype == CODON_F32, CODON_ERR_UNSUPPORTED, "conv2d_gated_fwd: dtype %d", d->dtype);
-  CODON_REQUIRE(gated_out == nullptr, CODON_ERR_UNSUPPORTED,
-                "conv2d_gated_emit_fwd: 16-bit only (the fp32 gated convs are matrix-pipe bound: their staging arithmetic is hidden)");
-  return conv2d_gated_fwd_f32(d, (const float*)pre, inputs, ch, sp, (const float*)w_packed, (float*)y, (hipStream_t)stream);
+  CODON_REQUIRE(!gated_out || (gated_out->coff >= 0 && gated_out->coff + d->cin <= gated_out->ctotal), CODON_ERR_BAD_ARG,
+                "conv2d_gated_emit_fwd: gated_out slice outside its buffer");
+  return conv2d_gated_fwd_f32(d, (const float*)pre, inputs, ch, sp, (const float*)w_packed, (float*)y, gated_out, (hipStream_t)stream);
 }
 
 int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,

@@ -49,6 +49,10 @@ struct ConvParams {
   const float* ch;
   const float* sp;
   long in_img, in_base;
+  // GATE, optional: the gate-applied input is ALSO written here (each tile its own pixels), so that a sibling conv on the
+  // same input runs plain (codon_conv2d_gated_emit_fwd)
+  float* gout;
+  long go_img, go_base;
   // FUSE only: the chained 1x1 (128 -> 64) applied to the tile while it is still in the accumulators
   const float* w2;  // [t2][t][lane][16]: W1[t2*32 + (lane&31)][t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
   float* y2;
@@ -154,9 +158,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   // chunk:  x = fma(pre, ch * sp, in)  exactly as cac_apply_kernel computes it.
   constexpr int NPOS = XR * XQ, PJ = (NPOS + NT - 1) / NT;
   unsigned poff[PJ];
+  unsigned pown = 0;                       // GATE: bit j = position j is one of the tile's own pixels (not halo), in the image
   float spv[GATE ? PJ : 1];
   const float* const inbase = GATE ? p.in2 + (long)b * p.in_img + p.in_base : nullptr;
   const float* const chp = GATE ? p.ch + (long)b * 64 : nullptr;
+  const bool emit = GATE && p.gout != nullptr;           // wave-uniform
+  float* const gobase = emit ? p.gout + (long)b * p.go_img + p.go_base : nullptr;
   {
     __amdgpu_buffer_rsrc_t sprsrc;
     if constexpr (GATE)
@@ -168,7 +175,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
       const int gy = ty0 + r - PAD, gx = tx0 + q - PAD;
       const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
       poff[j] = ok ? 4u * (unsigned)(gy * W + gx) : BUF_OOB;
-      if constexpr (GATE) spv[j] = buf_ld(sprsrc, poff[j], 0u);
+      if constexpr (GATE) {
+        spv[j] = buf_ld(sprsrc, poff[j], 0u);
+        if (ok && r >= PAD && r < PAD + TH && q >= PAD && q < PAD + TW) pown |= 1u << j;
+      }
     }
   }
   // Round 3: x and weight stages go global -> LDS by LDS-DMA (buffer_load_dword / dwordx4 ... lds): no staging registers,
@@ -212,14 +222,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
       }                                                                            \
     }                                                                              \
   }
-#define STORE_X(buf_)                                                              \
+#define STORE_X(chunk_, buf_)                                                      \
   if constexpr (!DMA) {                                                            \
     float* dst_ = xs0 + (buf_) * XSP + tid;                                        \
+    __amdgpu_buffer_rsrc_t gor_;                                                   \
+    if constexpr (GATE) { if (emit) gor_ = planes(gobase, (chunk_) * CK, CK); }    \
     _Pragma("unroll") for (int j = 0; j < PJ; ++j)                                 \
       if (NPOS % NT == 0 || tid + j * NT < NPOS) {                                 \
         _Pragma("unroll") for (int c = 0; c < CK; ++c) {                           \
-          if constexpr (GATE) dst_[c * NPOS + j * NT] = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]); \
-          else dst_[c * NPOS + j * NT] = xg_[c][j];                                \
+          if constexpr (GATE) {                                                    \
+            const float gv_ = fmaf(xg_[c][j], chs[c] * spv[j], xi_[c][j]);         \
+            dst_[c * NPOS + j * NT] = gv_;                                         \
+            if (emit) buf_st(gv_, gor_, ((pown >> j) & 1u) ? poff[j] : BUF_OOB, (unsigned)c * HW4); \
+          } else dst_[c * NPOS + j * NT] = xg_[c][j];                              \
         }                                                                          \
       }                                                                            \
   }
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   // prologue
   LOAD_X(0, 0);
   LOAD_W(0, 0);
-  STORE_X(0);
+  STORE_X(0, 0);
   STORE_W(0);
   CODON_TSTAMP(p.dbg, 1)
   if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's DMA pieces have landed
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
 #undef FETCH
 
     if (has_next) STORE_W((s + 1) & 1);
-    if (next_chunk) STORE_X((chunk + 1) & 1);
+    if (next_chunk) STORE_X(chunk + 1, (chunk + 1) & 1);
     if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier
     __syncthreads();
   }
@@ -543,6 +558,7 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
 #endif
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
+  p.gout = nullptr; p.go_img = p.go_base = 0;
   const unsigned dyn = (PSEG == 1 && small_grid(d)) ? solo_lds_pad(conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>) : 0u;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), dyn, stream, p);
   return check_launch("conv_mfma_f32_kernel");
@@ -559,7 +575,7 @@ int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
 
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
-                          const float* sp, const float* w, float* y, hipStream_t stream) {
+                          const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
   constexpr int TH = 4 * PSEG;
   ConvParams p;
   p.x = pre; p.w = w; p.y = y; p.res = nullptr;
@@ -569,6 +585,8 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = 0;
   p.in2 = (const float*)in2->data; p.in_img = in2->ctotal * HW; p.in_base = in2->coff * HW;
   p.ch = ch; p.sp = sp;
+  p.gout = gated_out ? (float*)gated_out->data : nullptr;
+  p.go_img = gated_out ? gated_out->ctotal * HW : 0; p.go_base = gated_out ? gated_out->coff * HW : 0;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;
@@ -588,18 +606,18 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
 
 template <int KS, int CIN, int COUT>
 static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
-                        const float* sp, const float* w, float* y, hipStream_t stream) {
-  if (small_grid(d)) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, stream);
-  return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, stream);
+                        const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
+  if (small_grid(d)) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, gated_out, stream);
+  return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, gated_out, stream);
 }
 
 int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
-                         const float* sp, const float* w, float* y, hipStream_t stream) {
+                         const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
-    case 5064064: return launch_gated<5, 64, 64>(d, pre, in2, ch, sp, w, y, stream);
-    case 3064064: return launch_gated<3, 64, 64>(d, pre, in2, ch, sp, w, y, stream);
-    case 3128064: return launch_gated<3, 128, 64>(d, pre, in2, ch, sp, w, y, stream);
+    case 5064064: return launch_gated<5, 64, 64>(d, pre, in2, ch, sp, w, y, gated_out, stream);
+    case 3064064: return launch_gated<3, 64, 64>(d, pre, in2, ch, sp, w, y, gated_out, stream);
+    case 3128064: return launch_gated<3, 128, 64>(d, pre, in2, ch, sp, w, y, gated_out, stream);
     default:
       set_error("conv2d_gated_fwd: no f32 kernel for k=%d cin=%d cout=%d", d->ksize, d->cin, d->cout);
       return CODON_ERR_UNSUPPORTED;
@@ -624,6 +642,7 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   p.x_img = d->x_ctotal * HW; p.y_img = d->y_ctotal * HW; p.r_img = res ? res->ctotal * HW : 0;
   p.x_base = d->x_coff * HW; p.y_base = d->y_coff * HW; p.r_base = res ? res->coff * HW : 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
+  p.gout = nullptr; p.go_img = p.go_base = 0;
   p.w2 = w_chain; p.y2 = (float*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;

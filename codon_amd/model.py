@@ -27,8 +27,9 @@ import os as _os
 
 # inference, 16-bit tensors: form the gate-apply in the consuming convs' staging (True) or as a pass (False); A/B switch
 GATED_16BIT = _os.environ.get("CODON_GATED16", "1") != "0"
-# 16-bit gated inference: the conv5x5 of a sibling pair applies the gate and EMITS the gated tensor, the conv3x3 reads it as
-# a plain conv (its staging is bound by the gate arithmetic otherwise: 1.00 vs 0.71 ms at 32x480x640).  0 = both gated (A/B)
+# gated inference: the conv5x5 of a sibling pair applies the gate and EMITS the gated tensor, the conv3x3 reads it as a plain
+# conv (its staging is bound by the gate arithmetic otherwise: bf16 1.00 vs 0.71 ms, fp32 5.41 vs 5.05 ms at 32x480x640).
+# 0 = both gated (A/B)
 GATED_EMIT = _os.environ.get("CODON_GATED_EMIT", "1") != "0"
 # inference on a grid too small to fill the chip (every conv launch < 256 workgroups: one 128 x 128 image is 128): the depth
 # and the colour stream of a block are independent up to the CAC gate -- run them on two HIP streams.  0 = one stream (A/B)
@@ -291,7 +292,7 @@ class _CODONBase(nn.Module):
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
         # 16-bit: with the emitting conv5x5 (GATED_EMIT) the training forward takes the same route -- the emitted tensor IS
         # the block input the backward needs, bit-identical to cac_apply's output, and the 7.5 GB apply pass is gone there too
-        emit16 = fused_stats and GATED_16BIT and GATED_EMIT and not split5
+        emit16 = GATED_EMIT and not split5 and ((fused_stats and GATED_16BIT) or (adt == torch.float32 and not keep))
         gated = not split5 and (((not keep) and (adt == torch.float32 or GATED_16BIT)) or (keep and emit16))
 
         emit16 = emit16 and gated

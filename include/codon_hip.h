@@ -151,7 +151,7 @@ int codon_conv2d_gated_fwd(const codon_conv_desc* d, const void* pre, const codo
  * tile, the values it staged) to the `gated_out` slice: `out` / `out_c` feed TWO convs (conv1 + conv2, conv4 + conv5,
  * CODON_x4.py:75-78) -- the first one applies the gate and emits x, the second reads it as a plain conv (codon_conv2d_fwd)
  * instead of repeating the gate arithmetic in its own staging.  gated_out must not alias `pre` / `inputs` (other tiles
- * still read their halos from them).  16-bit dtypes only (CODON_ERR_UNSUPPORTED for fp32). */
+ * still read their halos from them).  Any dtype. */
 int codon_conv2d_gated_emit_fwd(const codon_conv_desc* d, const void* pre, const codon_tensor* inputs, const float* ch,
                                 const float* sp, const void* w_packed, void* y, const codon_tensor* gated_out,
                                 codon_stream_t stream);

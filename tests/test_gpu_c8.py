@@ -297,17 +297,18 @@ def test_gated_conv_equals_apply_then_conv(kcc, dtype):
         assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 64 + cin:]).all()
 
 
-@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dtype", DT + [torch.float32])
 def test_inference_schedules_agree_bit_for_bit(dtype):
-    """16-bit inference has three schedules for `out*ad_CAC + inputs` (CODON_x4.py:89-91): a cac_apply pass, both sibling
+    """Inference has three schedules for `out*ad_CAC + inputs` (CODON_x4.py:89-91): a cac_apply pass, both sibling
     convs gated, or the conv5x5 gated + emitting and the conv3x3 plain on the emitted tensor (the default).  Same
     arithmetic, same rounding points: identical outputs."""
     import codon_amd
     from codon_amd import model as M
     dev = _dev()
     torch.manual_seed(3)
-    net = codon_amd.CODONNet().to(dev)
-    net.set_compute_dtype(dtype)
+    net = codon_amd.CODONNet().to(dev).eval()
+    if dtype != torch.float32:
+        net.set_compute_dtype(dtype)                     # fp32: gated / gated + emit (GATED_16BIT is not consulted)
     x = torch.rand((2, 1, 37, 70), device=dev)
     y = torch.rand((2, 1, 37, 70), device=dev)
     outs = []

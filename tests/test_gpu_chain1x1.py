@@ -149,6 +149,15 @@ def test_gated_conv_equals_apply_then_conv(shape, k, cin):
     y2 = torch.empty_like(y)
     ops.conv2d(Slice(oc, coff, cin), wp, Slice(y2), k, relu=True)
     assert torch.equal(y, y2)
+    # emit (codon_conv2d_gated_emit_fwd): the conv also writes the gated input it staged, every own pixel once, into a
+    # slice of a wider buffer -- bit for bit cac_apply's output
+    y3 = torch.full((B, 64, H, W), float("nan"), device=dev)
+    xg = torch.full((B, 64 + cin + 8, H, W), float("nan"), device=dev)
+    ops.conv2d_gated(Slice(pd, coff, cin), Slice(idv, coff, cin), chd, spd, wp, Slice(y3), k, relu=True,
+                     emit=Slice(xg, 64, cin))
+    assert torch.equal(y, y3)
+    assert torch.equal(xg[:, 64:64 + cin], oc[:, coff:coff + cin])
+    assert torch.isnan(xg[:, :64]).all() and torch.isnan(xg[:, 64 + cin:]).all()
     g = ch[:, :, None, None] * sp                                     # (B,64,H,W)
     xin = pre2 * torch.cat([g, g], 1) + in2
     ref = F.relu(F.conv2d(xin[:, coff:coff + cin], w, None, 1, k // 2))
