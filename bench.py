@@ -248,6 +248,8 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    per_rank = gather_rank_info(step_stats(evs), dist, rank, world)
+    model.check_packed(synchronize=False)
     if rank != 0:
         return None
     P = B * H * W
@@ -269,6 +271,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
                        "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
             "images_per_s": world * B * steps / dt,
             "step_events": step_stats(evs),
+            "per_rank_step_ms": [{k: st_[k] for k in ("median_ms", "min_ms", "max_ms")} if st_ else None for st_ in per_rank],
             "whole_step": {"tflops": tf, "frac_mfma_peak": tf / peak,
                            "flop_model": "3 x forward FLOPs (SURVEY.md 8d: dgrad + wgrad per conv)"},
             "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_c8_kernel<5>" if dtype == "bf16" else "conv_wgrad_f32_t16_kernel<5>") +
@@ -418,6 +421,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch images PER GPU whatever N. strong: --batch images IN TOTAL, split over the "
                          "N ranks (SURVEY.md 8e); the label goes into the JSON line")
+    ap.add_argument("--rccl-selfcheck", choices=["auto", "on", "off"], default="auto",
+                    help="before timing, run SURVEY 8(e)'s gradient-equality check on the product kernels over the process "
+                         "group (codon_amd.dist.grad_equality_selfcheck): `grad_equal` in rank 0's line.  auto = when N > 1")
     ap.add_argument("--no-script-pattern", action="store_true",
                     help="skip the single-image latencies at the reference script's image sizes (N = 1 default line only)")
     a = ap.parse_args()
@@ -449,6 +455,16 @@ def main():
 
     from codon_amd import BaseNet_RMCR_fuseRMCR, CODONNet, CODONNet16, ops
     B, H, W = (a.batch // world if a.scaling == "strong" else a.batch), a.height, a.width
+    selfcheck = None
+    if a.rccl_selfcheck == "on" or (a.rccl_selfcheck == "auto" and world > 1):
+        # first contact with the multi-rank path: is the averaged gradient the single-process gradient?  (never fatal:
+        # the line is still printed, with grad_equal false and the reason)
+        from codon_amd.dist import grad_equality_selfcheck
+        try:
+            selfcheck = grad_equality_selfcheck(dev)
+        except Exception as e:          # noqa: BLE001
+            selfcheck = {"grad_equal": False, "error": f"{type(e).__name__}: {e}"[:500]}
+        torch.cuda.empty_cache()
     ranks = gather_rank_info(rank_info(dev, local), dist, rank, world)
     versions = software_versions(a.backend if world > 1 else None)
     torch.manual_seed(0)
@@ -475,7 +491,11 @@ def main():
     if a.mode == "train":
         res = train_leg(model, x, y, dev, dist, rank, world, barrier, a.steps, a.warmup, a.dtype, a.scale, a.scaling)
         if rank == 0:
+            for r_, st_ in zip(ranks, res["per_rank_step_ms"]):
+                r_["train_step_ms"] = st_
             res["ranks"], res["versions"] = ranks, versions
+            if selfcheck is not None:
+                res["grad_equal"], res["rccl_selfcheck"] = selfcheck["grad_equal"], selfcheck
             print(json.dumps(res), flush=True)
         if dist is not None:
             dist.barrier()
@@ -485,6 +505,7 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             out = model(x, y)
+        model.check_packed()                # natural sync point: no forward so far ran on stale packed weights
         ops.PROFILE = {"key": (5, 128, 128), "events": []}
         dtype_label = "f32 via 3xf16-split MFMA (opt-in, not exact fp32)" if split else a.dtype
         step_ev = []
@@ -505,6 +526,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    fwd_per_rank = gather_rank_info(step_stats(step_ev), dist, rank, world)   # a straggler GPU shows up per rank
 
     res = None
     if rank == 0:
@@ -569,7 +591,11 @@ def main():
                 "parity": "passes the same RMSE <= 1e-4 fixtures as the exact path (tests/test_gpu_f16x3.py)"}
         res["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
         res["backend"] = (dist.get_backend() if dist is not None else None)
+        for r_, st_ in zip(ranks, fwd_per_rank):
+            r_["fwd_step_ms"] = {k: st_[k] for k in ("median_ms", "min_ms", "max_ms")} if st_ else None
         res["ranks"], res["versions"] = ranks, versions
+        if selfcheck is not None:
+            res["grad_equal"], res["rccl_selfcheck"] = selfcheck["grad_equal"], selfcheck
     if rank == 0 and rmcr:
         # no CAC gates: 5 x (518 activation elements + 250 MAC of the 5x5 2->1 spatial conv) less per pixel
         step_s_ = dt / a.steps
@@ -603,6 +629,8 @@ def main():
                               "peak_mem_gb": leg["peak_mem_gb"], "step_events": leg["step_events"],
                               "roofline": leg["roofline"], "allreduce_us": leg["allreduce_us"],
                               "allreduce_bytes": leg["allreduce_bytes"], "scaling": leg["scaling"]}
+            for r_, st_ in zip(res["ranks"], leg["per_rank_step_ms"]):
+                r_["train_step_ms"] = st_
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)

@@ -33,6 +33,13 @@ class Tensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("ctotal", C.c_int32), ("coff", C.c_int32)]
 
 
+WSUM_MAX = 32   # CODON_WSUM_MAX
+
+
+class WsumDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("data", C.c_void_p * WSUM_MAX), ("bytes", C.c_uint64 * WSUM_MAX)]
+
+
 _P, _I, _S = C.c_void_p, C.c_int32, C.c_size_t
 _TP = C.POINTER(Tensor)
 
@@ -82,6 +89,8 @@ SIGNATURES = {
     "codon_ssim_l1_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "codon_bicubic_upsample": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
+    "codon_weight_checksum_workspace_bytes": (_S, []),
+    "codon_weight_checksum": (C.c_int, [C.POINTER(WsumDesc), _P, _P, _I, _P, _P]),
 }
 
 _lock = threading.Lock()

@@ -8,8 +8,9 @@ CODON_x4.py:66-132.  Here forward keeps every activation the backward needs (cod
   * dL/dw = codon_conv2d_wgrad, accumulating across the 5 / 3 loop iterations that share weights
     (CODON_x4.py:74,122); 16-bit: the 1x1 convs' dL/dw and masked dL/dx come from one pass (codon_conv1x1_bwd);
   * CAC gate backward = ops.cac_backward (4 kernels);
-  * stem / head: stencil + 1-channel wgrad.
-Gradients w.r.t. the two input images are not produced (the reference never asks for them).
+  * stem / head: stencil + 1-channel wgrad;
+  * dL/d(input images) when x / y require grad (what the reference's autograd would return): the stems' 64 -> 1 dgrad
+    through the head stencil, plus the identity path of the final residual add for x.
 """
 from __future__ import annotations
 
@@ -88,7 +89,9 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         sibling convs run again from the saved block input (same kernels, same packed weights: bit-identical)."""
         if saved is not None:
             return saved
-        buf = scratch.setdefault("stage", new(128))
+        if "stage" not in scratch:            # one buffer for all 13 restage calls (setdefault would allocate each time)
+            scratch["stage"] = new(128)
+        buf = scratch["stage"]
         ops.conv2d(xs, model._packed(first[0]), Slice(buf, 0, 64), first[1], relu=True)
         ops.conv2d(xs, model._packed(second[0]), Slice(buf, 64, 64), second[1], relu=True)
         return buf

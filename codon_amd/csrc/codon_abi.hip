@@ -94,6 +94,9 @@ int ssim_fwd(int, int, int, const float*, const float*, float*, float*, double*,
 int l1_fwd(long, const float*, const float*, float*, int, double*, hipStream_t);
 int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*, float*, float, float, hipStream_t);
 
+size_t weight_checksum_workspace_bytes();
+int weight_checksum(const codon_wsum_desc*, void*, unsigned long long*, int, int*, hipStream_t);
+
 static bool slice_ok(const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + 64 <= t->ctotal; }
 
 static bool shape_ok(int b, int h, int w) { return b > 0 && h > 0 && w > 0 && (long)h * w < (1L << 31); }
@@ -543,6 +546,23 @@ int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, i
   CODON_REQUIRE(scale == 4 || scale == 8 || scale == 16, CODON_ERR_UNSUPPORTED, "bicubic_upsample: scale %d", scale);
   CODON_REQUIRE(shape_ok(batch, lr_height * scale, lr_width * scale), CODON_ERR_BAD_ARG, "bicubic_upsample: bad shape");
   return bicubic_upsample(batch, lr_height, lr_width, scale, lr, phase_weights, out, (hipStream_t)stream);
+}
+
+size_t codon_weight_checksum_workspace_bytes(void) { return weight_checksum_workspace_bytes(); }
+
+int codon_weight_checksum(const codon_wsum_desc* desc, void* ws, uint64_t* ref, int32_t mode, int32_t* flag,
+                          codon_stream_t stream) {
+  CODON_REQUIRE(desc && ws && ref && flag, CODON_ERR_BAD_ARG, "weight_checksum: null pointer");
+  CODON_REQUIRE(desc->n > 0 && desc->n <= CODON_WSUM_MAX && (mode == 0 || mode == 1), CODON_ERR_BAD_ARG,
+                "weight_checksum: n %d (1..%d), mode %d (0, 1)", desc->n, CODON_WSUM_MAX, mode);
+  uint64_t total = 0;
+  for (int t = 0; t < desc->n; ++t) {
+    CODON_REQUIRE(desc->data[t] && desc->bytes[t] % 16 == 0 && ((uintptr_t)desc->data[t] & 15) == 0, CODON_ERR_BAD_ARG,
+                  "weight_checksum: tensor %d must be 16-byte aligned with a multiple of 16 bytes", t);
+    total += desc->bytes[t];
+  }
+  CODON_REQUIRE(total / 16 < (1ull << 32), CODON_ERR_UNSUPPORTED, "weight_checksum: more than 64 GiB of weights");
+  return weight_checksum(desc, ws, (unsigned long long*)ref, mode, flag, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -519,7 +519,19 @@ static bool small_grid(const codon_conv_desc* d) {
 #endif
 template <class K>
 static unsigned solo_lds_pad(K kernel) {
-  static int pad = -1;                    // one per kernel instantiation; a racing first call computes the same value
+  // hipFuncSetAttribute acts on the CURRENT device's function object: one slot per (kernel instantiation, device), so
+  // every GPU of a single-process multi-GPU caller (nn.DataParallel, per-device threads) raises its own limit before its
+  // first padded launch.  A racing first call on a device computes and stores the same value.
+  constexpr int MAXDEV = 64;
+  static int pads[MAXDEV];
+  static bool init = [] { for (int i = 0; i < MAXDEV; ++i) pads[i] = -1; return true; }();
+  (void)init;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    (void)hipGetLastError();
+    return 0;                               // unknown device: launch unpadded (speed only)
+  }
+  int pad = __atomic_load_n(&pads[dev], __ATOMIC_ACQUIRE);
   if (pad < 0) {
     int want = 0;
     hipFuncAttributes a;
@@ -531,6 +543,7 @@ static unsigned solo_lds_pad(K kernel) {
     }
     (void)hipGetLastError();
     pad = want;
+    __atomic_store_n(&pads[dev], pad, __ATOMIC_RELEASE);
   }
   return (unsigned)pad;
 }

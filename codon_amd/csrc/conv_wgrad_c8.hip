@@ -215,7 +215,10 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(gg + ((long)ty0 * W + tx0)), 0, (int)C8_OOB, C8_RSRC_FLAGS);
     // 9 tiles in 10 touch no image border: their offsets are tile independent (3 instructions per piece instead of ~30)
-    const bool interior = ty0 >= PAD && ty0 + TH + PAD <= H && tx0 >= PAD && tx0 + TW + PAD <= W;   // wave-uniform
+    // (every STAGED column must be inside the image row -- the tile is XC columns wide from tx0 - PAD, which for KS = 3 is two
+    // more than TW + 2 PAD: with `tx0 + TW + PAD <= W` a W % 32 == 1 image let them wrap into the next row, and past the end
+    // of x on the last row of the last plane)
+    const bool interior = ty0 >= PAD && ty0 + TH + PAD <= H && tx0 >= PAD && tx0 - PAD + XC <= W;   // wave-uniform
     if (interior) {
 #pragma unroll
       for (int k = 0; k < PPW; ++k) {

@@ -89,3 +89,61 @@ def shard_batch(n_images: int, rank: int, world: int):
     base, rem = divmod(n_images, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5):
+    """First-contact check of the data-parallel path on whatever backend the process group runs (RCCL over xGMI on the
+    8-GPU node; gloo in rehearsals): SURVEY.md 8(e)'s correctness test on the product kernels, small enough to run before
+    every multi-rank benchmark.  Ranks build DIFFERENT parameters, rank 0's are broadcast, every rank runs the HIP forward
+    + backward on ITS image of a world-sized batch (per-image-mean L1 loss), one all-reduce of the flat gradient; then
+    each rank computes the gradient of the whole batch by itself and compares, in fp32 and in bf16.  Returns
+    {"grad_equal": bool over all ranks, "worst_rel": {dtype: max over tensors and ranks}, "first_forward_equal": bool}."""
+    import numpy as np
+    from .model import CODONNet
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    H, W = size
+    rng = np.random.default_rng(4242)
+    x = torch.from_numpy(rng.uniform(0, 1, size=(world, 1, H, W)).astype(np.float32)).to(device)
+    y = torch.from_numpy(rng.uniform(0, 1, size=(world, 1, H, W)).astype(np.float32)).to(device)
+    t = torch.from_numpy(rng.uniform(0, 1, size=(world, 1, H, W)).astype(np.float32)).to(device)
+    state = torch.random.get_rng_state()
+    torch.manual_seed(1000 + rank)
+    m = CODONNet().to(device).train()
+    torch.random.set_rng_state(state)
+    with torch.no_grad():
+        m(x[:1], y[:1])                                   # packs this rank's OWN weights: the broadcast must drop them
+    gs = GradSync(m)
+    gs.broadcast_parameters(0)
+    worst, ok = {}, True
+    with torch.no_grad():
+        o = m(x[:1], y[:1]).float()
+    digest = torch.stack([o.double().sum(), o.double().abs().sum(), o.double().pow(2).sum()])
+    lo_, hi_ = digest.clone(), digest.clone()
+    if world > 1:
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    first_equal = bool(torch.equal(lo_, hi_))
+    for dt, tag in ((None, "f32"), (torch.bfloat16, "bf16")):
+        m.set_compute_dtype(dt)
+        gs.zero_grad()
+        (m(x[rank:rank + 1], y[rank:rank + 1]) - t[rank:rank + 1]).abs().mean().backward()
+        gs.all_reduce_grads()
+        avg = gs.flat.clone()
+        gs.zero_grad()
+        (m(x, y) - t).abs().mean().backward()
+        w, off = 0.0, 0
+        for p in gs.params:
+            n = p.numel()
+            a, b = avg[off:off + n].double(), gs.flat[off:off + n].double()
+            w = max(w, float((a - b).norm() / (b.norm() + 1e-30)))
+            off += n
+        wt = torch.tensor([w], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        worst[tag] = float(wt.item())
+        ok = ok and worst[tag] <= tol and bool(torch.isfinite(avg).all())
+    m.check_packed()
+    return {"grad_equal": bool(ok and first_equal), "first_forward_equal": first_equal, "worst_rel": worst, "tol": tol,
+            "ranks": world, "what": "N-rank averaged HIP gradient vs the same rank's single-process HIP gradient on the "
+                                    "concatenated batch, worst tensor over all ranks (SURVEY.md 8e)"}

@@ -34,16 +34,24 @@ class GraphedCODON:
     def _weight_tags(self):
         return [(p.data_ptr(), p._version) for p in self.model.parameters()]
 
-    def stale(self) -> bool:
-        """True when a parameter was replaced or modified (autograd-visibly) after capture.  Writes through `.data`
-        are invisible here, exactly as for the packed-weight cache (model.invalidate_packed)."""
-        return self._weight_tags() != self._tags
+    def stale(self, synchronize: bool = False) -> bool:
+        """True when a parameter was replaced or modified after capture: autograd-visibly (host-side tags), or through
+        `.data` -- the captured forward carries the model's weight-checksum launch (model._WeightGuard), so a replay on
+        such weights sets the guard's host-visible flag; with synchronize=True every replay enqueued so far is judged."""
+        if self._weight_tags() != self._tags:
+            return True
+        try:
+            self.model.check_packed(synchronize=synchronize)
+        except RuntimeError:
+            return True
+        return False
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if x.shape != self.x.shape:
             raise RuntimeError(f"GraphedCODON was captured for {tuple(self.x.shape)}, got {tuple(x.shape)}")
         if self.stale():
-            raise RuntimeError("GraphedCODON: the model's parameters changed after capture; build a new GraphedCODON")
+            raise RuntimeError("GraphedCODON: the model's parameters changed after capture (visibly, or through `.data`: "
+                               "stale packed weights were replayed); build a new GraphedCODON")
         self.x.copy_(x)
         self.y.copy_(y)
         self.graph.replay()

@@ -34,22 +34,107 @@ GATED_EMIT = _os.environ.get("CODON_GATED_EMIT", "1") != "0"
 # inference on a grid too small to fill the chip (every conv launch < 256 workgroups: one 128 x 128 image is 128): the depth
 # and the colour stream of a block are independent up to the CAC gate -- run them on two HIP streams.  0 = one stream (A/B)
 TWO_STREAMS = _os.environ.get("CODON_TWO_STREAMS", "1") != "0"
-_HALF_STREAMS: Dict[int, tuple] = {}
+_HALF_STREAMS: Dict[tuple, tuple] = {}
 
 
-def _half_chip_streams(dev):
-    """Two side streams for the two halves of a block.  (Streams created with hipExtStreamCreateWithCUMask were tried to keep
-    the two launches on disjoint CUs: 6.0 ms instead of 4.4 with ANY mask, also the full one -- the external streams'
-    event traffic; what separates the launches instead is the LDS request of the small-grid kernels, conv_mfma_f32.hip.)"""
+def _half_chip_streams(dev, main_stream):
+    """Two side streams for the two halves of a block, private to (device, calling stream, host thread): independent
+    callers -- DataParallel replica threads, a hipGraph capture in one thread beside eager launches in another -- never
+    share a side stream, so they get neither false cross-dependencies nor a stream that is in capture mode under them.
+    (Streams created with hipExtStreamCreateWithCUMask were tried to keep the two launches on disjoint CUs: 6.0 ms
+    instead of 4.4 with ANY mask, also the full one -- the external streams' event traffic; what separates the launches
+    instead is the LDS request of the small-grid kernels, conv_mfma_f32.hip.)"""
+    import threading
     i = dev.index if dev.index is not None else torch.cuda.current_device()
-    if i not in _HALF_STREAMS:
-        _HALF_STREAMS[i] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-    return _HALF_STREAMS[i]
+    key = (i, main_stream.cuda_stream, threading.get_ident())
+    if key not in _HALF_STREAMS:
+        _HALF_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _HALF_STREAMS[key]
 
 
 # debug: re-pack on every cache hit and compare, so a write through `.data` after the first forward (the reference's own
-# init idiom is m.weight.data.normal_(), CODON_x4.py:50-53) raises instead of silently using stale packed weights
+# init idiom is m.weight.data.normal_(), CODON_x4.py:50-53) raises IN THE SAME CALL instead of one call later (_WeightGuard)
 VERIFY_PACKED = _os.environ.get("CODON_VERIFY_PACKED", "0") != "0"
+# the per-forward checksum launch of _WeightGuard; 0 = off (A/B of its cost only)
+WEIGHT_GUARD = _os.environ.get("CODON_WEIGHT_GUARD", "1") != "0"
+
+_STALE_MSG = ("codon_amd: a conv weight was written through `.data` (or another path that does not bump Tensor._version, "
+              "e.g. `m.weight.data.normal_()`) after its packed MFMA image was built -- the forward(s) since then used the "
+              "stale packed weights; call model.invalidate_packed() after such writes")
+
+
+class _WeightGuard:
+    """Default-on detector of stale packed weights.  The pack cache is keyed on (data_ptr, Tensor._version) of each weight,
+    which a write through `.data` does not change.  Every forward launches ONE small kernel (codon_weight_checksum) over
+    the raw bytes of the 17 MFMA conv weights: the first launch after the host-visible key changed records the checksum the
+    packed images are built from, every later one compares and, on a mismatch, sets a flag in pinned host memory.  The
+    host reads that word (no synchronisation) at the start of every forward / graph replay and in check_packed(): the
+    stale forward itself has already been enqueued by then, the NEXT call raises.  Per (thread, stream) state, because
+    the kernel's workspace and reference slot are ordered by the stream they are used on."""
+
+    def __init__(self):
+        self.tag = None            # host-visible key of all 17 weights the pack cache was last valid for
+        self.flag = None           # pinned int32[1], written by the kernel
+        self.flag_np = None
+        self.states = {}           # (thread id, stream handle) -> [tag, workspace, desc, tensor whose last word is the reference]
+        self.disabled = False
+
+    def tripped(self) -> bool:
+        return self.flag_np is not None and bool(self.flag_np[0])
+
+    def reset(self):
+        self.tag = None
+        self.states.clear()
+        if self.flag_np is not None:
+            self.flag_np[0] = 0
+
+    def run(self, model, dev):
+        import ctypes as C
+        import threading
+        if self.tripped():
+            raise RuntimeError(_STALE_MSG)
+        ws = [getattr(model, n).weight for n in _MFMA_CONVS]
+        tag = tuple((w.data_ptr(), w._version, w.dtype) for w in ws) + (dev,)
+        if tag != self.tag:
+            # some weight changed visibly: EVERY packed image is rebuilt, so that all of them belong to the checksum
+            # recorded below (a partial rebuild could fold an earlier invisible write into the new reference)
+            model._pack_cache.clear()
+            self.tag = tag
+            self.disabled = any((w.data_ptr() % 16) or ((w.numel() * w.element_size()) % 16) or not w.is_contiguous()
+                                for w in ws)
+        if self.disabled:
+            return
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.flag_np = self.flag.numpy()
+        stream = torch.cuda.current_stream(dev)
+        key = (threading.get_ident(), stream.cuda_stream)
+        st = self.states.get(key)
+        lib = L.load()
+        if st is None or st[1].device != dev:
+            n = lib.codon_weight_checksum_workspace_bytes() // 8 + 1          # + the reference slot (last word)
+            st = self.states[key] = [None, torch.zeros(n, dtype=torch.int64, device=dev), None, None]
+        mode = 1
+        if st[0] != tag:
+            d = L.WsumDesc()
+            d.n = len(ws)
+            for i, w in enumerate(ws):
+                d.data[i] = w.data_ptr()
+                d.bytes[i] = w.numel() * w.element_size()
+            # under hipGraph capture a recording launch would be replayed as a recording launch and never compare: take
+            # the reference another stream recorded for these very weights (GraphedCODON's warm-up runs; they are joined
+            # before the capture starts) and capture a COMPARING launch
+            donor = None
+            if torch.cuda.is_current_stream_capturing():
+                donor = next((o for o in self.states.values() if o is not st and o[0] == tag and o[1].device == dev), None)
+            st[0], st[2] = tag, d
+            st[3], mode = (donor[3], 1) if donor is not None else (st[1], 0)
+        ref = st[3]
+        with torch.cuda.device(dev):
+            L.check(lib.codon_weight_checksum(C.byref(st[2]), C.c_void_p(st[1].data_ptr()),
+                                              C.c_void_p(ref.data_ptr() + 8 * (ref.numel() - 1)), mode,
+                                              C.c_void_p(self.flag.data_ptr()), C.c_void_p(stream.cuda_stream)),
+                    "weight_checksum")
 
 
 class Conv2dParams(nn.Module):
@@ -145,6 +230,7 @@ class _CODONBase(nn.Module):
             self.attention_c5 = ChannelGate(64)
             self.attention_s5 = CAC_spatial()
         self._pack_cache: Dict[str, tuple] = {}
+        self._wguard: Optional[_WeightGuard] = None
         self.compute_dtype: Optional[torch.dtype] = None
         self.conv_precision: str = "exact"
         self.recompute: bool = False
@@ -205,8 +291,33 @@ class _CODONBase(nn.Module):
         weight; optimizer steps, load_state_dict, .to()/.half()/.cuda() and every other autograd-visible in-place
         op change one of those.  Writes THROUGH `.data` (`w.data.normal_()`, `dist.broadcast(w.data)`) do not bump
         `_version`: after such a write call this method (codon_amd.dist.GradSync does, and load_state_dict / _apply
-        are hooked below)."""
+        are hooked below).  A forgotten call does not go unnoticed: _WeightGuard raises on the next forward."""
         self._pack_cache.clear()
+        g = self.__dict__.get("_wguard")
+        if g is not None:
+            g.reset()
+        return self
+
+    def _guard(self, dev):
+        """One checksum launch per forward over the 17 MFMA conv weights (see _WeightGuard)."""
+        if not WEIGHT_GUARD:
+            return
+        g = self.__dict__.get("_wguard")
+        if g is None:
+            g = self._wguard = _WeightGuard()
+        g.run(self, dev)
+
+    def check_packed(self, synchronize: bool = True):
+        """Raise if a forward since the last (re)pack ran on stale packed weights (a `.data` write the cache key cannot
+        see).  synchronize=True waits for the device first, so every forward enqueued so far has been judged -- the
+        natural places: before trusting a result (smoke(), bench warm-up), GraphedCODON.stale()."""
+        g = self.__dict__.get("_wguard")
+        if g is None:
+            return self
+        if synchronize and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if g.tripped():
+            raise RuntimeError(_STALE_MSG)
         return self
 
     def _apply(self, fn, *a, **k):
@@ -224,11 +335,13 @@ class _CODONBase(nn.Module):
     def __getstate__(self):  # pickle / deepcopy: drop the device-side cache
         d = self.__dict__.copy()
         d["_pack_cache"] = {}
+        d["_wguard"] = None
         return d
 
     def _replicate_for_data_parallel(self):
         r = super()._replicate_for_data_parallel()
         r._pack_cache = {}
+        r._wguard = None
         return r
 
     # -- forward ---------------------------------------------------------------------------
@@ -268,6 +381,7 @@ class _CODONBase(nn.Module):
         backward needs is kept in fresh buffers; without it buffers are reused across blocks."""
         B, _, H, W = x.shape
         dev = x.device
+        self._guard(dev)
         adt = self._act_dtype()
         new = lambda c: ops.new_act(B, c, H, W, adt, dev)
         P = self._packed
@@ -325,7 +439,16 @@ class _CODONBase(nn.Module):
         # small grids (inference): two HIP streams, fork before the streams of a block, join at its gate
         two = TWO_STREAMS and (not keep) and dev.type == "cuda" and B * ((H + 3) // 4) * ((W + 31) // 32) <= 256
         main_s = torch.cuda.current_stream(dev) if two else None
-        halves = _half_chip_streams(dev) if two else None
+        halves = _half_chip_streams(dev, main_s) if two else None
+        if two:
+            # every packed weight image is built (or found) on the CALLER's stream before the fork: an image first built
+            # on a side stream would live in that stream's allocator pool and could be recycled there while main-stream
+            # kernels still read it
+            for n_ in ("conv1", "conv2", "conv4", "conv5", "conv7", "conv8", "conv9", "conv11"):
+                P(n_)
+            for n5_, n1_ in (("conv3", "confuse"), ("conv6", "confuse_c"), ("conv10", "confuse_fuse")):
+                P(n5_)
+                P(n1_, chain_mode)
 
         class _on_half:
             """`with _on_half(k):` runs the body on half-chip stream k, ordered after everything issued so far on the main one."""
@@ -467,10 +590,13 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
             setattr(self, name, Conv2dParams(ci, co, k, he_init=True))
         self.relu = nn.ReLU()
         self._pack_cache: Dict[str, tuple] = {}
+        self._wguard: Optional[_WeightGuard] = None
         self.compute_dtype: Optional[torch.dtype] = None
         self.conv_precision: str = "exact"
 
     set_compute_dtype = _CODONBase.set_compute_dtype
+    _guard = _CODONBase._guard
+    check_packed = _CODONBase.check_packed
     set_conv_precision = _CODONBase.set_conv_precision
     _act_dtype = _CODONBase._act_dtype
     _packed = _CODONBase._packed
@@ -496,6 +622,7 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
         idt = x.dtype
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape
+        self._guard(x.device)
         adt = self._act_dtype()
         new = lambda c: ops.new_act(B, c, H, W, adt, x.device)
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
@@ -554,6 +681,7 @@ class BaseNet_RMCR_fuseRMCR_cross(_CODONBase):
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape
         dev = x.device
+        self._guard(dev)
         adt = self._act_dtype()
         new = lambda c: ops.new_act(B, c, H, W, adt, dev)
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()

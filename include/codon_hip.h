@@ -317,6 +317,27 @@ int codon_bicubic_upsample(int32_t batch, int32_t lr_height, int32_t lr_width, i
                            const float* lr, const float* phase_weights, float* out,
                            codon_stream_t stream);
 
+/* ---- stale-packed-weight guard -------------------------------------------------------------------
+ * The packed MFMA weight images are cached on the host side under (data_ptr, Tensor._version) of each weight; the
+ * reference's own init idiom writes THROUGH `.data` (`m.weight.data.normal_()`, CODON_X4/CODON_x4.py:50-53), which
+ * that key cannot see.  codon_weight_checksum is launched once per forward: it folds a position-dependent 64-bit
+ * checksum over the raw bytes of the n listed tensors (bytes[t] % 16 == 0, 16-byte aligned) and
+ *   mode 0: stores it in *ref (device memory; taken when the packed images are (re)built);
+ *   mode 1: compares it with *ref and, on a mismatch, stores 1 to *flag -- host-visible (pinned, device-mapped)
+ *           memory that the caller polls without synchronising; never cleared by the kernel.
+ * ws: codon_weight_checksum_workspace_bytes() of device memory, ZEROED once by the caller, private to one stream
+ * (the kernel leaves its arrival counter at zero).  Defined in codon_amd/csrc/wsum.hip. */
+#define CODON_WSUM_MAX 32
+typedef struct codon_wsum_desc {
+  int32_t n;
+  int32_t reserved;
+  const void* data[CODON_WSUM_MAX];
+  uint64_t bytes[CODON_WSUM_MAX];
+} codon_wsum_desc;
+size_t codon_weight_checksum_workspace_bytes(void);
+int codon_weight_checksum(const codon_wsum_desc* desc, void* ws, uint64_t* ref, int32_t mode, int32_t* flag,
+                          codon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

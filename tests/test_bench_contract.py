@@ -34,7 +34,7 @@ def test_bench_line_single_gpu_small_shape():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["cores"] >= 1
     fb = d["fwd_bwd"]                                   # the iters/sec (fwd+bwd) half of the BASELINE metric
     assert fb["it_per_s"] > 0 and fb["dtype"] == "bf16" and fb["steps"] >= 3 and fb["rccl_ranks"] == 1
-    assert d["rccl_ranks"] == 1
+    assert d["rccl_ranks"] == 1 and "grad_equal" not in d          # the self-check is a multi-rank leg
 
 
 @pytest.mark.gpu
@@ -43,6 +43,7 @@ def test_bench_self_launches_two_ranks():
               "--width", "96"])
     assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo"
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    assert d["grad_equal"] is True, d.get("rccl_selfcheck")
     assert d["fwd_bwd"]["rccl_ranks"] == 2 and d["fwd_bwd"]["global_batch"] == 4
     # whole-job throughput: both ranks' images are counted
     assert abs(d["value"] - 2 * 2 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
@@ -65,6 +66,14 @@ def test_bench_four_ranks_strong_scaling_and_diagnostics():
     assert fb["step_events"]["n"] == fb["steps"] and fb["step_events"]["min_ms"] <= fb["step_events"]["median_ms"]
     assert d["step_events"]["n"] == d["steps"]
     assert fb["roofline"]["launches_timed"] == 13 * fb["steps"] and 0 < fb["roofline"]["frac"] < 1.05
+    # 8-GPU first-contact checklist, rehearsed on 4 gloo ranks: the gradient-equality self-check ran
+    # over the process group before timing, and every rank's own step times are in the record (a straggler is visible)
+    sc = d["rccl_selfcheck"]
+    assert d["grad_equal"] is True and sc["first_forward_equal"] is True and sc["ranks"] == 4, sc
+    assert set(sc["worst_rel"]) == {"f32", "bf16"} and all(v <= sc["tol"] for v in sc["worst_rel"].values()), sc
+    for r in d["ranks"]:
+        assert r["fwd_step_ms"]["min_ms"] <= r["fwd_step_ms"]["median_ms"] <= r["fwd_step_ms"]["max_ms"]
+        assert r["train_step_ms"]["min_ms"] <= r["train_step_ms"]["median_ms"]
 
 
 @pytest.mark.gpu

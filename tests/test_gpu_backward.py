@@ -9,7 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import codon_oracle as orc
-from tests.util import load_case, rel_rmse, rmse, target_for
+from tests.util import BF16_GRAD_CASES, load_case, rel_rmse, rmse, target_for
 
 GRAD_TOL = 1e-4
 
@@ -290,6 +290,59 @@ def test_bf16_training_gradients_vs_fp32_oracle():
     assert (num / den) ** 0.5 <= 5e-2
 
 
+BF16_GRAD_RATIO = 1.25      # the rule test_forward_bf16_vs_reference_module_run_in_bf16 uses for the forward
+
+
+@pytest.mark.parametrize("name", BF16_GRAD_CASES)
+def test_bf16_gradients_vs_reference_bf16_autograd(name):
+    """The bf16 BACKWARD pinned to the reference's own bf16 behaviour (tools/make_golden_r4.py): the reference module cast
+    to bfloat16, forward + autograd on CPU, is 0.5-9e-2 away from its float64 twin, tensor by tensor (same upstream
+    gradient).  The HIP bf16 path (bf16 activations / activation gradients, fp32 accumulate, fp32 parameter gradients)
+    must be no further from fp64 than BF16_GRAD_RATIO x that, for EVERY one of the 44 tensors -- the 25 CAC parameter
+    tensors (MLP weights / biases, 5x5 spatial conv: CAC_module.py:30-35,88) included -- on the stored subsample; and its
+    whole gradient vector no further than the reference's."""
+    z, variant, sd, x, y = load_case(name)
+    up = torch.from_numpy(z["upstream"]).cuda()
+    for mode in ("fp32 master weights + bf16 compute (configs[2])", "whole-module .bfloat16()"):
+        m = _model(variant, sd)
+        if mode.startswith("fp32"):
+            m.set_compute_dtype(torch.bfloat16)
+            out = m(x.cuda(), y.cuda())
+        else:
+            m = m.bfloat16()
+            out = m(x.cuda().bfloat16(), y.cuda().bfloat16())
+        assert rel_rmse(out.detach().float().cpu(), z["out_fp64"]) <= 1.25 * rel_rmse(z["out_bf16"], z["out_fp64"])
+        out.backward(up.to(out.dtype))
+        ratios, n = {}, 0
+        num_h = num_r = den = 0.0
+        for k, p in m.named_parameters():
+            if k.startswith("attention_c5") or k.startswith("attention_s5"):
+                assert p.grad is None
+                continue
+            s = int(z["stride." + k])
+            g64, gref = z["g64." + k].astype(np.float64), z["gbf16." + k].astype(np.float64)
+            got = p.grad.detach().float().flatten()[::s].cpu().double().numpy()
+            assert np.isfinite(got).all(), k
+            e_hip = np.linalg.norm(got - g64) / np.linalg.norm(g64)
+            e_ref = float(z["err_sub." + k])
+            ratios[k] = e_hip / e_ref
+            num_h += float(((got - g64) ** 2).sum())
+            num_r += float(((gref - g64) ** 2).sum())
+            den += float((g64 ** 2).sum())
+            n += 1
+        assert n == 44
+        worst = max(ratios.items(), key=lambda kv: kv[1])
+        cac = {k: v for k, v in ratios.items() if k.startswith("attention_")}
+        print(f"[{name}] {mode}: HIP-bf16 error / reference-bf16 error (both vs fp64): worst {worst[0]} {worst[1]:.2f}, "
+              f"median {float(np.median(list(ratios.values()))):.2f}, CAC tensors worst {max(cac.values()):.2f} "
+              f"median {float(np.median(list(cac.values()))):.2f}; whole vector HIP {(num_h / den) ** 0.5:.3e} "
+              f"reference {(num_r / den) ** 0.5:.3e}")
+        bad = {k: round(v, 3) for k, v in ratios.items() if not v <= BF16_GRAD_RATIO}
+        assert not bad, (mode, bad)
+        assert len(cac) == 25
+        assert num_h <= num_r, mode
+
+
 def test_input_gradients_match_oracle_autograd():
     """dL/dx and dL/dy (the reference's autograd provides them when the inputs require grad): the stems' 64 -> 1 dgrad
     through the head stencil, plus the identity path of the final residual add for x."""
@@ -377,21 +430,88 @@ def test_recompute_switch_gives_identical_gradients(dtype):
 
 def test_packed_weight_verification_catches_data_writes(monkeypatch):
     """A write through `.data` after the first forward does not bump Tensor._version, so the packed-weight cache cannot
-    see it (documented; model.invalidate_packed() is the remedy).  CODON_VERIFY_PACKED=1 turns the silent staleness
-    into an error."""
+    see it.  DEFAULT behaviour (no environment switch): every forward carries one weight-checksum launch
+    (model._WeightGuard, csrc/wsum.hip); the forward enqueued right after the write still runs on the stale packed
+    weights, the NEXT call -- or check_packed() at any synchronisation point -- raises.  CODON_VERIFY_PACKED=1 (debug)
+    raises in the same call.  model.invalidate_packed() is the remedy."""
     import codon_amd.model as M
+    assert M.WEIGHT_GUARD and not M.VERIFY_PACKED
     sd = orc.he_state("x4", seed=43)
     m = _model("x4", sd).eval()
     x = torch.rand((1, 1, 16, 24), device="cuda")
     with torch.no_grad():
         o0 = m(x, x)
+        assert torch.equal(m(x, x), o0)
+        m.check_packed()                         # clean so far
         m.conv3.weight.data.mul_(0.5)            # the reference's own init idiom writes through .data (CODON_x4.py:50-53)
-        assert torch.equal(m(x, x), o0)          # stale packed weights: the documented hazard
+        o1 = m(x, x)                             # enqueued on stale packed weights; its checksum launch notices
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o0)
+        with pytest.raises(RuntimeError, match="stale"):
+            m(x, x)
+        with pytest.raises(RuntimeError, match="stale"):
+            m.check_packed()
+        m.invalidate_packed()
+        o2 = m(x, x)
+        assert not torch.equal(o2, o0)
+        m.check_packed()
+        # a single changed BIT in the last weight of the list is seen too, and in training mode as well
+        m.conv11.weight.data.view(torch.int32)[-1, -1, -1, -1] ^= 1
+        m(x, x)
+        with pytest.raises(RuntimeError, match="stale"):
+            m.check_packed()
+        m.invalidate_packed()
+        # visible updates (optimizer-style in-place ops bump _version) never trip it
+        m.conv3.weight.mul_(2.0)
+        o3 = m(x, x)
+        m.check_packed()
+        assert not torch.equal(o3, o2)
+        # the debug switch: same-call detection
+        m.conv3.weight.data.mul_(0.5)
         monkeypatch.setattr(M, "VERIFY_PACKED", True)
         with pytest.raises(RuntimeError, match="stale"):
             m(x, x)
+        monkeypatch.setattr(M, "VERIFY_PACKED", False)
         m.invalidate_packed()
-        assert not torch.equal(m(x, x), o0)
+        m(x, x)
+        m.check_packed()
+
+
+def test_weight_guard_in_graph_replay_and_threads():
+    """The captured forward carries a COMPARING checksum launch (the reference comes from GraphedCODON's warm-up runs):
+    a replay after a `.data` write trips the guard; a second host thread on its own stream has its own guard state."""
+    import threading
+    from codon_amd.graph import GraphedCODON
+    sd = orc.he_state("x4", seed=44)
+    m = _model("x4", sd).eval()
+    x = torch.rand((1, 1, 24, 32), device="cuda")
+    with torch.no_grad():
+        gm = GraphedCODON(m, x, x)
+        o0 = gm(x, x)
+        assert not gm.stale(synchronize=True) and torch.equal(gm(x, x), m(x, x))
+        errs = []
+
+        def other():
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    for _ in range(3):
+                        assert torch.equal(m(x, x), o0)
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        t = threading.Thread(target=other)
+        t.start()
+        for _ in range(3):
+            m(x, x)
+        t.join()
+        assert not errs, errs
+        m.check_packed()
+        m.conv8.weight.data.add_(0.01)
+        gm(x, x)                                 # replay on stale packed weights: its checksum launch notices
+        assert gm.stale(synchronize=True)
+        with pytest.raises(RuntimeError):
+            gm(x, x)
 
 
 @pytest.mark.gpu

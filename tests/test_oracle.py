@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import codon_oracle as orc
-from tests.util import GOLDEN_CASES, load_case, rel_rmse, rmse, target_for
+from tests.util import BF16_GRAD_CASES, GOLDEN_CASES, load_case, rel_rmse, rmse, target_for
 
 # fp32 tolerance: the reference's own fp32-vs-fp64 floor is 1.2e-5 RMSE on He-init
 # outputs of std ~5; the restatement uses the same ATen ops, so it
@@ -70,6 +70,33 @@ def test_grads_match_reference(name):
         assert abs(float(g.double().norm()) - float(z["gradnorm." + k])) <= 1e-4 * float(z["gradnorm." + k]) + 1e-12, k
         n += 1
     assert n == 44
+
+
+@pytest.mark.parametrize("name", BF16_GRAD_CASES)
+def test_fp64_and_bf16_autograd_match_reference_fixture(name):
+    """tools/make_golden_r4.py: the reference module's autograd in float64 and in bfloat16 from one fixed upstream
+    gradient.  The oracle run in float64 must reproduce the fp64 gradients (stored as fp32: 1e-6), and run in bfloat16 the
+    reference's own bf16 gradients (same ATen ops in the same order); the stored error figures must follow from the
+    stored samples."""
+    z, variant, sd, x, y = load_case(name)
+    assert len(BF16_GRAD_CASES) >= 2
+    up = torch.from_numpy(z["upstream"])
+    tgt = target_for(x)
+    _, g64, o64 = orc.grads({k: v.double() for k, v in sd.items()}, x.double(), y.double(), tgt.double(), upstream=up.double())
+    assert rmse(o64, z["out_fp64"]) <= 1e-12
+    _, gb, ob = orc.grads({k: v.bfloat16() for k, v in sd.items()}, x.bfloat16(), y.bfloat16(), tgt.bfloat16(),
+                          upstream=up.bfloat16())
+    assert rel_rmse(ob.float(), z["out_bf16"]) <= 1e-6
+    assert len(g64) == 44
+    for k in g64:
+        s = int(z["stride." + k])
+        ref64, refb = z["g64." + k], z["gbf16." + k]
+        assert rel_rmse(g64[k].flatten()[::s], ref64) <= 1e-6, k
+        assert abs(float(g64[k].norm()) - float(z["norm64." + k])) <= 1e-9 * float(z["norm64." + k]), k
+        assert rel_rmse(gb[k].float().flatten()[::s], refb) <= 1e-6, k
+        e = np.linalg.norm(refb.astype(np.float64) - ref64) / np.linalg.norm(ref64.astype(np.float64))
+        assert abs(e - float(z["err_sub." + k])) <= 1e-5 * e + 1e-9, k
+        assert 1e-3 < float(z["err_full." + k]) < 0.15, k          # bf16: 5e-3 ... 9e-2 per tensor in the reference itself
 
 
 def test_state_dict_contract(golden_dir):

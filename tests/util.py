@@ -15,6 +15,10 @@ GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and
 BF16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16ref_") and f.endswith(".npz"))
 
 
+# the reference MODULE run forward AND backward in bfloat16 on CPU + its float64 twin (tools/make_golden_r4.py)
+BF16_GRAD_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16grad_") and f.endswith(".npz"))
+
+
 def load_case(name):
     z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
     B, H, W = (int(v) for v in z["shape"])
