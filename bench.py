@@ -57,7 +57,7 @@ def synth_inputs(B, H, W, scale, seed, dev):
     return x.contiguous(), y.contiguous()
 
 
-def pmc_traffic(kernel_prefix, B, H, W, pattern="r*_fwd_b32_480x640_pmc_hbm.json"):
+def pmc_traffic(kernel_prefix, B, H, W, pattern="r*_fwd_b32_480x640_pmc*.json"):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/: FETCH_SIZE x2-corrected +
     WRITE_SIZE, separate passes of the same bench command).  Counters cannot be read from inside this process, so this
     is the latest committed measurement for this exact workload, or None."""
@@ -277,9 +277,9 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_c8_kernel<5>" if dtype == "bf16" else "conv_wgrad_f32_t16_kernel<5>") +
                                    " 128->128 + its fixed-order reduce (dW of conv3 / conv6 / conv10)",
                          "achieved": wach, "peak": peak, "unit": "TFLOP/s", "frac": wach / peak,
-                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5", B, H, W,
+                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5, false, 128, 128>", B, H, W,
                                                 "r*_bf16_train_b32_480x640_pmc.json") if dtype == "bf16" else None,
-                         "traffic_note": "PMC average over the 5x5 wgrad launches of a step (128->128 and 64->64 shapes share the kernel)",
+                         "traffic_note": "PMC bytes per launch of the 128->128 launches only (the kernel name carries the shape)",
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "alg_bytes_per_launch": 2 * 128 * esz * P, "launches_timed": len(wev), "avg_launch_ms": wms,
                          "flop_per_launch": wflop},

@@ -90,7 +90,10 @@ struct WgradC8Params {
   long dy_img, dy_base;
 };
 
-template <class E, int KS, bool DG = false>
+// TAG_CI / TAG_CO: the channel shape of the launch, carried in the kernel NAME only (the code reads p.cin / p.cout): the
+// 5x5 weight gradients of the 128 -> 128 and the 64 -> 64 convs run the same code on the same 256-workgroup grid, and
+// per-shape rows in the rocprofv3 kernel statistics / PMC tables are what the roofline accounting needs (0 = untagged)
+template <class E, int KS, bool DG = false, int TAG_CI = 0, int TAG_CO = 0>
 __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
   static_assert(!DG || KS == 1, "the fused input gradient exists for the 1x1 conv only");
   typedef typename E::vec8 vec8;
@@ -585,8 +588,12 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
   const bool f16 = d->dtype == CODON_F16;
   if (d->ksize == 5) {
-    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, dim3(Wc8Waves<5>::value * 64), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, dim3(Wc8Waves<5>::value * 64), 0, stream, p);
+    const dim3 blk(Wc8Waves<5>::value * 64);
+    const int shape = d->cin * 1000 + d->cout;
+    if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 5>), grid, blk, 0, stream, p);
+    else if (shape == 128128) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5, false, 128, 128>), grid, blk, 0, stream, p);
+    else if (shape == 64064) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5, false, 64, 64>), grid, blk, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 5>), grid, blk, 0, stream, p);
   } else if (d->ksize == 3) {
     if (f16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 3>), grid, dim3(Wc8Waves<3>::value * 64), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 3>), grid, dim3(Wc8Waves<3>::value * 64), 0, stream, p);

@@ -12,7 +12,10 @@
 
 namespace codon {
 
-constexpr int WS_BLOCKS = 1024, WS_THREADS = 256;   // 262 144 threads: <= 2 vectors each for the 7.4 MB of fp32 weights
+// 64 workgroups x 1024 threads (one arrival atomic each: with 1024 workgroups the 1024 same-address atomics alone took
+// ~40 us -- measured: the first version cost a 1 x 128 x 128 forward 50 us); a thread owns WS_U vectors per sweep, all
+// requested before the first is used.  7.4 MB of fp32 weights = one sweep.
+constexpr int WS_BLOCKS = 64, WS_THREADS = 1024, WS_U = 8;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -26,27 +29,51 @@ __device__ __forceinline__ unsigned long long wsum_term(unsigned w, unsigned lon
   return ((unsigned long long)w + 0x9E3779B9ull) * (2ull * i + 1ull) * 0x9E3779B97F4A7C15ull;
 }
 
+__device__ __forceinline__ unsigned long long wsum_wave_sum(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(WS_THREADS) void wsum_kernel(const WsumArgs a, unsigned long long* __restrict__ ws,
                                                            unsigned long long* __restrict__ ref, int mode,
                                                            int* __restrict__ flag) {
   __shared__ unsigned long long red[WS_THREADS / 64];
+  __shared__ unsigned s_nvec[CODON_WSUM_MAX + 1];
+  __shared__ const u32x4* s_data[CODON_WSUM_MAX];
   __shared__ bool last;
-  const unsigned total = a.nvec[a.n];
-  unsigned long long acc = 0;
-  for (unsigned q = blockIdx.x * WS_THREADS + threadIdx.x; q < total; q += WS_BLOCKS * WS_THREADS) {
-    int t = 0;
-    while (q >= a.nvec[t + 1]) ++t;       // <= 17 scalar-table compares
-    const u32x4 v = __builtin_nontemporal_load(a.data[t] + (q - a.nvec[t]));
-    const unsigned long long i = 4ull * q;
-    acc += wsum_term(v.x, i) + wsum_term(v.y, i + 1) + wsum_term(v.z, i + 2) + wsum_term(v.w, i + 3);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)acc, o), hi = __shfl_xor((unsigned)(acc >> 32), o);
-    acc += ((unsigned long long)hi << 32) | lo;
-  }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  const int tid = threadIdx.x;
+  if (tid <= CODON_WSUM_MAX) s_nvec[tid] = a.nvec[tid];
+  if (tid < CODON_WSUM_MAX) s_data[tid] = a.data[tid];
   __syncthreads();
-  if (threadIdx.x == 0) {
+  const unsigned total = s_nvec[CODON_WSUM_MAX];     // == nvec[n]: the host pads the prefix table
+  unsigned long long acc = 0;
+  for (unsigned base = blockIdx.x * (WS_THREADS * WS_U); base < total; base += WS_BLOCKS * WS_THREADS * WS_U) {
+    u32x4 v[WS_U];
+#pragma unroll
+    for (int u = 0; u < WS_U; ++u) {
+      const unsigned q = base + u * WS_THREADS + tid;
+      int t = 0;                            // tensor of vector q: 5-step bisection of the 33-entry prefix table
+#pragma unroll
+      for (int step = CODON_WSUM_MAX / 2; step > 0; step >>= 1)
+        if (q >= s_nvec[t + step]) t += step;
+      v[u] = q < total ? __builtin_nontemporal_load(s_data[t] + (q - s_nvec[t])) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < WS_U; ++u) {
+      const unsigned q = base + u * WS_THREADS + tid;
+      if (q < total) {
+        const unsigned long long i = 4ull * q;
+        acc += wsum_term(v[u].x, i) + wsum_term(v[u].y, i + 1) + wsum_term(v[u].z, i + 2) + wsum_term(v[u].w, i + 3);
+      }
+    }
+  }
+  acc = wsum_wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
     unsigned long long s = 0;
     for (int k = 0; k < WS_THREADS / 64; ++k) s += red[k];
     ws[1 + blockIdx.x] = s;
@@ -55,26 +82,20 @@ __global__ __launch_bounds__(WS_THREADS) void wsum_kernel(const WsumArgs a, unsi
   }
   __syncthreads();
   if (!last) return;
-  // the last block to arrive folds the per-block sums (every one of them is visible: fence above, acquire below)
+  // the last workgroup to arrive folds the per-workgroup sums (all visible: release fence above, acquire fence below)
   __threadfence();
-  unsigned long long s = 0;
-  for (int k = threadIdx.x; k < WS_BLOCKS; k += WS_THREADS) s += __atomic_load_n(&ws[1 + k], __ATOMIC_RELAXED);
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)s, o), hi = __shfl_xor((unsigned)(s >> 32), o);
-    s += ((unsigned long long)hi << 32) | lo;
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s = 0;
-    for (int k = 0; k < WS_THREADS / 64; ++k) s += red[k];
-    ws[0] = 0;                                            // ready for the next launch on this workspace
-    ws[1 + WS_BLOCKS] = s;                                // last value seen (diagnostics)
-    if (mode == 0) {
-      *ref = s;
-    } else if (s != *ref) {
-      __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible, sticky
+  if (tid < 64) {
+    unsigned long long s = 0;
+    for (int k = tid; k < WS_BLOCKS; k += 64) s += __atomic_load_n(&ws[1 + k], __ATOMIC_RELAXED);
+    s = wsum_wave_sum(s);
+    if (tid == 0) {
+      ws[0] = 0;                                          // ready for the next launch on this workspace
+      ws[1 + WS_BLOCKS] = s;                              // last value seen (diagnostics)
+      if (mode == 0) {
+        *ref = s;
+      } else if (s != *ref) {
+        __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible, sticky
+      }
     }
   }
 }

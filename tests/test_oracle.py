@@ -75,28 +75,34 @@ def test_grads_match_reference(name):
 @pytest.mark.parametrize("name", BF16_GRAD_CASES)
 def test_fp64_and_bf16_autograd_match_reference_fixture(name):
     """tools/make_golden_r4.py: the reference module's autograd in float64 and in bfloat16 from one fixed upstream
-    gradient.  The oracle run in float64 must reproduce the fp64 gradients (stored as fp32: 1e-6), and run in bfloat16 the
-    reference's own bf16 gradients (same ATen ops in the same order); the stored error figures must follow from the
-    stored samples."""
-    z, variant, sd, x, y = load_case(name)
-    assert len(BF16_GRAD_CASES) >= 2
-    up = torch.from_numpy(z["upstream"])
-    tgt = target_for(x)
-    _, g64, o64 = orc.grads({k: v.double() for k, v in sd.items()}, x.double(), y.double(), tgt.double(), upstream=up.double())
-    assert rmse(o64, z["out_fp64"]) <= 1e-12
-    _, gb, ob = orc.grads({k: v.bfloat16() for k, v in sd.items()}, x.bfloat16(), y.bfloat16(), tgt.bfloat16(),
-                          upstream=up.bfloat16())
-    assert rel_rmse(ob.float(), z["out_bf16"]) <= 1e-6
-    assert len(g64) == 44
-    for k in g64:
-        s = int(z["stride." + k])
-        ref64, refb = z["g64." + k], z["gbf16." + k]
-        assert rel_rmse(g64[k].flatten()[::s], ref64) <= 1e-6, k
-        assert abs(float(g64[k].norm()) - float(z["norm64." + k])) <= 1e-9 * float(z["norm64." + k]), k
-        assert rel_rmse(gb[k].float().flatten()[::s], refb) <= 1e-6, k
-        e = np.linalg.norm(refb.astype(np.float64) - ref64) / np.linalg.norm(ref64.astype(np.float64))
-        assert abs(e - float(z["err_sub." + k])) <= 1e-5 * e + 1e-9, k
-        assert 1e-3 < float(z["err_full." + k]) < 0.15, k          # bf16: 5e-3 ... 9e-2 per tensor in the reference itself
+    gradient, on several input variants.  The oracle run in float64 must reproduce the fp64 gradients (stored as fp32:
+    1e-6), and run in bfloat16 the reference's own bf16 behaviour (same ATen ops in the same order): its stored
+    gradients on variant 0, its stored error figures on the others."""
+    from tests.util import bf16grad_inputs
+    z, variant, sd, _, _ = load_case(name)
+    B, H, W = (int(v) for v in z["shape"])
+    assert len(BF16_GRAD_CASES) >= 2 and int(z["nv"]) >= 8
+    for v in (0, 3):                                        # two of the variants keep the CPU suite short
+        x, y = bf16grad_inputs(v, B, H, W)
+        up = torch.from_numpy(z[f"v{v}.upstream"])
+        tgt = target_for(x)
+        _, g64, o64 = orc.grads({k: t.double() for k, t in sd.items()}, x.double(), y.double(), tgt.double(),
+                                upstream=up.double())
+        _, gb, ob = orc.grads({k: t.bfloat16() for k, t in sd.items()}, x.bfloat16(), y.bfloat16(), tgt.bfloat16(),
+                              upstream=up.bfloat16())
+        if v == 0:
+            assert rmse(o64, z["out_fp64"]) <= 1e-12 and rel_rmse(ob.float(), z["out_bf16"]) <= 1e-6
+        assert len(g64) == 44
+        for k in g64:
+            s = int(z["stride." + k])
+            ref64 = z[f"v{v}.g64.{k}"]
+            assert rel_rmse(g64[k].flatten()[::s], ref64) <= 1e-6, (v, k)
+            got_b = gb[k].float().flatten()[::s].double().numpy()
+            e = np.linalg.norm(got_b - ref64) / np.linalg.norm(ref64.astype(np.float64))
+            assert abs(e - float(z[f"v{v}.err_sub.{k}"])) <= 1e-4 * e + 1e-9, (v, k)
+            if v == 0:
+                assert rel_rmse(got_b, z["gbf16." + k]) <= 1e-6, k
+            assert 1e-3 < float(z[f"v{v}.err_full.{k}"]) < 0.6, (v, k)      # bf16: 3e-3 ... 4.5e-1 per tensor in the reference itself
 
 
 def test_state_dict_contract(golden_dir):

@@ -19,6 +19,16 @@ BF16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16re
 BF16_GRAD_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16grad_") and f.endswith(".npz"))
 
 
+def bf16grad_inputs(v, B, H, W):
+    """Inputs of variant v of a bf16grad_* fixture (tools/make_golden_r4.py::variant_inputs)."""
+    if v == 0:
+        return orc.kat_inputs(B, H, W)
+    g = np.random.default_rng(1000 + v)
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    return x, y
+
+
 def load_case(name):
     z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
     B, H, W = (int(v) for v in z["shape"])

@@ -7,9 +7,18 @@ only in the build container, writes data only; earlier fixtures are left untouch
                CODON_x4.py:66-132 / CAC_module.py:38-94 -- beside the float64 twin of the same net on the same inputs.
                Both backward passes start from the SAME upstream gradient dL/d(out) = sign(out_fp64 - target) / N (the
                L1 loss's gradient on the fp64 output: the sign is a discontinuity, fixing it isolates the backward pass).
-               Per used parameter tensor (44): every `stride`-th element of the fp64 gradient and of the reference-bf16
-               gradient, their full L2 norms, and the reference-bf16 error vs fp64 on the full tensor and on the stored
-               subsample.  tests/test_gpu_backward.py holds the HIP bf16 path to <= RATIO x that error, tensor by tensor.
+
+               NV input variants per case (same weights; variant v: x, y uniform in [0,1] from numpy default_rng(1000 + v);
+               variant 0 keeps the KAT inputs).  Why several: the bf16 error of a SMALL parameter tensor (the 25 CAC
+               tensors: 8 ... 1024 values, sums over a few hundred pixels with heavy cancellation, arg-max routing) is
+               dominated by a handful of discrete events -- in the reference's own bf16 run it spans 6e-3 ... 9e-2 from one
+               block's gate to the next -- so ONE realisation of it says little; pooled over NV problems it is a
+               statistic that another implementation can be held to.
+
+               Per variant and used parameter tensor (44): every `stride`-th element of the fp64 gradient (fp32 storage),
+               the reference-bf16 error vs fp64 on that subsample and on the full tensor; for variant 0 also the
+               reference-bf16 subsample itself.  tests/test_gpu_backward.py holds the HIP bf16 path, tensor by tensor, to
+               <= RATIO x the reference's error, both pooled (RMS) over the variants.
 """
 import os
 import sys
@@ -30,7 +39,18 @@ CASES = [
     ("bf16grad_he0_x4_2x24x20", "x4", "he", (2, 24, 20)),
     ("bf16grad_he1_x16_1x40x56", "x16", "he1", (1, 40, 56)),
 ]
-MAXN = 8192
+NV = 8
+MAXN = 1024
+
+
+def variant_inputs(v, B, H, W):
+    """Inputs of variant v (tests/util.py::bf16grad_inputs restates this)."""
+    if v == 0:
+        return orc.kat_inputs(B, H, W)
+    g = np.random.default_rng(1000 + v)
+    x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32))
+    return x, y
 
 
 def grads_of(net, x, y, up):
@@ -51,39 +71,45 @@ def main():
     for name, variant, wkind, (B, H, W) in CASES:
         net = mg.load_reference(variant)
         sd = orc.he_state(variant, seed=SEEDS[wkind])
-        x, y = orc.kat_inputs(B, H, W)
-        tgt = mg.target_for(x)
-        net.load_state_dict(sd, strict=True)
-        net.train()
-        with torch.no_grad():
-            o64 = net.double()(x.double(), y.double())
-        up = (torch.sign(o64 - tgt.double()) / o64.numel()).float()
-        _, g64 = grads_of(net, x.double(), y.double(), up.double())
-        ob, gb = grads_of(net.bfloat16(), x.bfloat16(), y.bfloat16(), up)
-        net.float()
-        rec = {"shape": np.array([B, H, W]), "variant": variant, "weights": wkind, "upstream": up.numpy(),
-               "out_fp64": o64.numpy(), "out_bf16": ob.float().numpy()}
-        assert len(g64) == 44 and set(g64) == set(gb)
-        worst = (0.0, None)
-        for k in g64:
-            stride, s64 = mg.sub(g64[k], MAXN)
-            _, sb = mg.sub(gb[k], MAXN)
-            rec["g64." + k] = s64.astype(np.float32)
-            rec["gbf16." + k] = sb.astype(np.float32)
-            rec["stride." + k] = np.int64(stride)
-            rec["norm64." + k] = np.float64(g64[k].norm())
-            rec["normbf16." + k] = np.float64(gb[k].norm())
-            e_full = float((gb[k] - g64[k]).norm() / g64[k].norm())
-            e_sub = float(np.linalg.norm(sb - s64) / np.linalg.norm(s64))
-            rec["err_full." + k] = np.float64(e_full)
-            rec["err_sub." + k] = np.float64(e_sub)
-            worst = max(worst, (e_full, k))
-            print(f"  {k:40s} n {g64[k].numel():7d} ref-bf16 vs fp64: full {e_full:.3e} subsample {e_sub:.3e}")
+        rec = {"shape": np.array([B, H, W]), "variant": variant, "weights": wkind, "nv": np.int64(NV)}
+        pooled = {}
+        for v in range(NV):
+            x, y = variant_inputs(v, B, H, W)
+            tgt = mg.target_for(x)
+            net.float()
+            net.load_state_dict(sd, strict=True)
+            net.train()
+            with torch.no_grad():
+                o64 = net.double()(x.double(), y.double())
+            up = (torch.sign(o64 - tgt.double()) / o64.numel()).float()
+            _, g64 = grads_of(net, x.double(), y.double(), up.double())
+            ob, gb = grads_of(net.bfloat16(), x.bfloat16(), y.bfloat16(), up)
+            assert len(g64) == 44 and set(g64) == set(gb)
+            rec[f"v{v}.upstream"] = up.numpy()
+            rec[f"v{v}.out_err"] = np.float64((ob.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
+            if v == 0:
+                rec["out_fp64"], rec["out_bf16"] = o64.numpy(), ob.float().numpy()
+            for k in g64:
+                stride, s64 = mg.sub(g64[k], MAXN)
+                _, sb = mg.sub(gb[k], MAXN)
+                s64 = s64.astype(np.float32)
+                rec[f"v{v}.g64.{k}"] = s64
+                if v == 0:
+                    rec["stride." + k] = np.int64(stride)
+                    rec["gbf16." + k] = sb.astype(np.float32)
+                n64 = float(np.linalg.norm(s64.astype(np.float64)))
+                assert n64 > 0, (name, v, k)
+                e_sub = float(np.linalg.norm(sb - s64.astype(np.float64)) / n64)
+                rec[f"v{v}.err_sub.{k}"] = np.float64(e_sub)
+                rec[f"v{v}.err_full.{k}"] = np.float64(float((gb[k] - g64[k]).norm() / g64[k].norm()))
+                pooled.setdefault(k, []).append(e_sub)
         path = os.path.join(mg.GOLD, name + ".npz")
         np.savez_compressed(path, **rec)
-        eo = float((ob.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
-        print(f"{name}: output bf16-vs-fp64 rel-RMSE {eo:.3e}; worst gradient tensor {worst[1]} {worst[0]:.3e} "
-              f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+        print(f"{name}: reference bf16 vs fp64, per tensor over {NV} input variants (subsample): min / RMS / max")
+        for k, es in pooled.items():
+            print(f"  {k:40s} {min(es):.3e} {float(np.sqrt(np.mean(np.square(es)))):.3e} {max(es):.3e}")
+        print(f"  output rel-RMSE per variant: {[round(float(rec[f'v{v}.out_err']), 4) for v in range(NV)]} -> "
+              f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":

@@ -97,7 +97,9 @@ def alg_bytes(name, P, es, mode):
              "head_c8_kernel": 64 * es * P + 8 * P, "head_kernel": 64 * 4 * P + 8 * P,
              "stem_c8_kernel": 64 * es * P + 4 * P, "stem_kernel": 64 * 4 * P + 4 * P,
              "conv1x1_c8_kernel<C8Bf16, 64, 128>": (64 + 128 + 128) * es * P,
-             "cac_bwd_apply_c8_kernel": (2 + 2 + 2 + 2) * 64 * es * P, "cac_bwd_reduce_c8_kernel": 4 * 64 * es * P}
+             # per block: g_out, pre in; g_pre, g_in out (2 x 64 channels each) = 8 x 64; blocks 3..0 also READ the running
+             # g_in (accumulate): 10 x 64 -- a training step launches 1 + 4 of them: 9.6 x 64 on average
+             "cac_bwd_apply_c8_kernel": 9.6 * 64 * es * P, "cac_bwd_reduce_c8_kernel": 4 * 64 * es * P}
     for k, v in table.items():
         if name.startswith(k):
             return (v, "single role")

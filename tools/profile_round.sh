@@ -1,28 +1,49 @@
 #!/bin/bash
-# Run ON THE GPU BOX (gpurun -- bash tools/profile_round.sh r02): bench records + rocprofv3 summaries of one round.
+# Run ON THE GPU BOX (gpurun -- bash tools/profile_round.sh r04): bench records + rocprofv3 summaries of one round.
 # Everything lands under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+# Every rocprofv3 command puts the program itself (python3 bench.py ...) directly after "--"; counters are collected in
+# their own runs (no trace domains besides --kernel-trace), FETCH_SIZE / WRITE_SIZE / clock+busy in separate passes.
+# One stderr file per command (round 3 wrote five runs into one .err: only the last survived).
 set -e -o pipefail
-tag=${1:-r02}
+tag=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py"
-echo "== default bench line"; $B --steps 5 --warmup 2 > $OUT/${tag}_bench_default.json 2> $OUT/${tag}_bench_default.err
-echo "== kernel trace, forward + fwd_bwd leg"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_prof_default -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${tag}_prof_default.log 2>&1
-echo "== PMC FETCH_SIZE"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${tag}_pmc_fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fwd-bwd > $OUT/${tag}_pmc_fetch.log 2>&1
-echo "== PMC WRITE_SIZE"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${tag}_pmc_write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fwd-bwd > $OUT/${tag}_pmc_write.log 2>&1
-python3 $ROOT/tools/pmc_hbm.py $OUT/${tag}_pmc_fetch $OUT/${tag}_pmc_write $OUT/${tag}_fwd_b32_480x640_pmc_hbm.json > $OUT/${tag}_pmc_hbm.txt
-echo "== other configs"
-$B --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${tag}_bench_bf16.json 2> $OUT/${tag}_other.err
-$B --mode train --dtype bf16 --steps 5 --warmup 2 > $OUT/${tag}_train_bf16.json 2> $OUT/${tag}_other.err
-$B --scale 8 --batch 16 --height 960 --width 1280 --steps 3 --warmup 1 --no-cpu-baseline --no-fwd-bwd > $OUT/${tag}_bench_x8_f32.json 2> $OUT/${tag}_other.err
-$B --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${tag}_bench_x16_bf16.json 2> $OUT/${tag}_other.err
-$B --model rmcr --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${tag}_bench_rmcr_f32.json 2> $OUT/${tag}_other.err
-echo "== bf16 training kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_prof_train_bf16 -- python3 $ROOT/bench.py --mode train --dtype bf16 --steps 3 --warmup 1 > $OUT/${tag}_prof_train_bf16.log 2>&1
-find $OUT/${tag}_prof_default $OUT/${tag}_prof_train_bf16 -name "*kernel_stats.csv" | head
+run() {   # run <name> <bench args...>: JSON line -> <tag>_<name>.json, stderr -> <tag>_<name>.err
+  local name=$1; shift
+  echo "== $name"; $B "$@" > $OUT/${tag}_${name}.json 2> $OUT/${tag}_${name}.err
+}
+pmc3() {  # pmc3 <label> <out.json> <mode> <esize> <bench args...>: FETCH / WRITE / busy passes + the merged table
+  local label=$1 out=$2 mode=$3 es=$4; shift 4
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== $label: pmc $c"
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${tag}_${label}_$c -- python3 $ROOT/bench.py "$@" --steps 1 --warmup 0 > $OUT/${tag}_${label}_$c.log 2>&1
+  done
+  echo "== $label: pmc clock + matrix-pipe busy"
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/${tag}_${label}_busy -- python3 $ROOT/bench.py "$@" --steps 1 --warmup 0 > $OUT/${tag}_${label}_busy.log 2>&1
+  python3 $ROOT/tools/pmc_report.py $OUT/${tag}_${label}_FETCH_SIZE $OUT/${tag}_${label}_WRITE_SIZE $OUT/${tag}_${label}_busy $OUT/$out 32 480 640 $mode $es | tee $OUT/${tag}_${label}_pmc.txt
+  find $OUT/${tag}_${label}_FETCH_SIZE $OUT/${tag}_${label}_WRITE_SIZE $OUT/${tag}_${label}_busy -name "*.csv" -size +8M -delete
+}
+trace() { # trace <label> <stats.csv name> <bench args...>
+  local label=$1 out=$2; shift 2
+  echo "== $label: kernel trace"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_${label}_trace -- python3 $ROOT/bench.py "$@" > $OUT/${tag}_${label}_trace.log 2>&1
+  f=$(find $OUT/${tag}_${label}_trace -name "*kernel_stats.csv" | head -1); test -n "$f"; cp "$f" $OUT/$out
+  find $OUT/${tag}_${label}_trace -name "*kernel_trace.csv" -delete
+}
+
+run bench_default --steps 5 --warmup 2
+trace default ${tag}_default_bench_kernel_stats.csv --steps 3 --warmup 1 --no-cpu-baseline --no-script-pattern
+pmc3 fwd ${tag}_fwd_b32_480x640_pmc.json fwd 4 --no-cpu-baseline --no-fwd-bwd --no-script-pattern
+trace bf16fwd ${tag}_bf16_fwd_b32_480x640_kernel_stats.csv --dtype bf16 --no-cpu-baseline --no-fwd-bwd --steps 3 --warmup 1
+pmc3 bf16fwd ${tag}_bf16_fwd_b32_480x640_pmc.json fwd 2 --dtype bf16 --no-cpu-baseline --no-fwd-bwd
+trace bf16train ${tag}_bf16_train_b32_480x640_kernel_stats.csv --mode train --dtype bf16 --no-cpu-baseline --steps 3 --warmup 1
+pmc3 bf16train ${tag}_bf16_train_b32_480x640_pmc.json train 2 --mode train --dtype bf16 --no-cpu-baseline
+run bench_bf16 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
+run train_bf16 --mode train --dtype bf16 --steps 10 --warmup 2
+run bench_x8_f32 --scale 8 --batch 16 --height 960 --width 1280 --steps 3 --warmup 1 --no-cpu-baseline --no-fwd-bwd
+run bench_x16_bf16 --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 --steps 5 --warmup 2 --no-cpu-baseline
+run bench_rmcr_f32 --model rmcr --steps 3 --warmup 1 --no-cpu-baseline
 echo done
