@@ -24,6 +24,9 @@ from .ops import Slice
 
 # 16-bit: dL/dw and dL/dx of the three 128 -> 64 1x1 convs in one pass each (codon_conv1x1_bwd); 0 = two kernels (A/B)
 FUSED_1X1_BWD = _os.environ.get("CODON_FUSED_1X1_BWD", "1") != "0"
+# 16-bit: the CAC gate backward without its apply pass -- dL/d(pre) is formed in the staging of the 1x1 backward that
+# consumes it, dL/d(inputs) accumulates in the reduce pass (ops.cac_backward_fused); 0 = the four-kernel form (A/B)
+FUSED_CAC_BWD = _os.environ.get("CODON_FUSED_CAC_BWD", "1") != "0"
 
 # parameters in a fixed order: the flat gradient buffer of codon_amd.dist uses the same order
 _CONVS = ["input", "conv_input", "conv1", "conv2", "conv3", "confuse", "input_c", "conv_input_c", "conv4", "conv5",
@@ -98,9 +101,12 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
 
     fused1 = ops.is_c8(adt) and FUSED_1X1_BWD
 
-    def bwd1x1(name, xs: Slice, gs: Slice, gxs: Slice):
+    fused_cac = fused1 and FUSED_CAC_BWD
+
+    def bwd1x1(name, xs: Slice, gs: Slice, gxs: Slice, gate=None, fcat_base=0):
         """both gradients of a 1x1 conv on a ReLU output xs: dW (accumulated over the shared uses) and gx = (W^T g) * [xs > 0];
-        16-bit: one pass over xs and gs (codon_conv1x1_bwd), else the wgrad + the masked dgrad conv."""
+        16-bit: one pass over xs and gs (codon_conv1x1_bwd), else the wgrad + the masked dgrad conv.  gate: gs is the block's
+        dL/d(out) and the conv's output gradient is formed from it while staging (codon_conv1x1_bwd_gated)."""
         if not fused1:
             wgrad(name, xs, gs, 1)
             ops.conv2d(gs, Pd(name), gxs, 1, relu_mask=xs)
@@ -109,7 +115,10 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         first = key not in G
         if first:
             G[key] = torch.empty_like(getattr(model, name).weight, dtype=torch.float32)
-        ops.conv1x1_bwd(xs, gs, Pd(name), gxs, G[key], accumulate=not first)
+        if gate is not None:
+            ops.conv1x1_bwd_gated(xs, gs, Pd(name), gxs, G[key], gate, fcat_base, accumulate=not first)
+        else:
+            ops.conv1x1_bwd(xs, gs, Pd(name), gxs, G[key], accumulate=not first)
 
     def wgrad(name, xs: Slice, gs: Slice, k: int):
         key = name + ".weight"
@@ -162,19 +171,28 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     # ---- MC + CAC blocks 4..0                                                           :74-118
     in2 = S["in2"]
     g_in2 = new(128)                                # running dL/d[inputs | inputs_c]
-    g_pre2 = new(128)
+    g_pre2 = None if fused_cac else new(128)
     for i in (4, 3, 2, 1, 0):
         Bk = S[f"blk{i}"]
         xin, r2, r2_c, pre2 = Bk["x"], Bk["r2"], Bk["r2_c"], Bk["pre2"]
         ac, asp = getattr(model, f"attention_c{i}"), getattr(model, f"attention_s{i}")
         if debug is not None:
             debug[f"g_oc{i}"] = g_oc.clone()
-        dw1, db1, dw2, db2, dws = ops.cac_backward(
-            Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
-            Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
-            f32(asp.spatial.conv.weight),
-            Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
-            accumulate_in=(i != 4))
+        gate = None
+        if fused_cac:
+            # no apply pass, no g_pre2: the two 1x1 backward launches below read g_oc itself (depth half first; the depth
+            # chain overwrites only channels 0..63 of g_oc / g_x before the colour chain reads 64..127)
+            dw1, db1, dw2, db2, dws, gate = ops.cac_backward_fused(
+                Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
+                Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                f32(asp.spatial.conv.weight), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64), accumulate_in=(i != 4))
+        else:
+            dw1, db1, dw2, db2, dws = ops.cac_backward(
+                Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
+                Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
+                f32(asp.spatial.conv.weight),
+                Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
+                accumulate_in=(i != 4))
         G[f"attention_c{i}.mlp.1.weight"], G[f"attention_c{i}.mlp.1.bias"] = dw1, db1
         G[f"attention_c{i}.mlp.3.weight"], G[f"attention_c{i}.mlp.3.bias"] = dw2, db2
         G[f"attention_s{i}.spatial.conv.weight"] = dws
@@ -185,7 +203,10 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             g_x, acc0 = g_in2, True
         # depth stream: pre = confuse(r2); r2 = relu(conv3(stage)); stage = [relu(conv1(x)) | relu(conv2(x))]
         stage = restage(Bk["stage"], Slice(xin, 0, 64), ("conv1", 3), ("conv2", 5))
-        bwd1x1("confuse", Slice(r2), Slice(g_pre2, 0, 64), Slice(g_r2))
+        if gate is not None:
+            bwd1x1("confuse", Slice(r2), Slice(g_oc, 0, 64), Slice(g_r2), gate, 64)      # depth = Fcat channels 64..127
+        else:
+            bwd1x1("confuse", Slice(r2), Slice(g_pre2, 0, 64), Slice(g_r2))
         wgrad("conv3", Slice(stage), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv3"), Slice(g_stage), 5, relu_mask=Slice(stage))
         wgrad("conv1", Slice(xin, 0, 64), Slice(g_stage, 0, 64), 3)
@@ -194,7 +215,10 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True)
         # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
         stage_c = restage(Bk["stage_c"], Slice(xin, 64, 64), ("conv4", 5), ("conv5", 3))
-        bwd1x1("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), Slice(g_r2))
+        if gate is not None:
+            bwd1x1("confuse_c", Slice(r2_c), Slice(g_oc, 64, 64), Slice(g_r2), gate, 0)  # colour = Fcat channels 0..63
+        else:
+            bwd1x1("confuse_c", Slice(r2_c), Slice(g_pre2, 64, 64), Slice(g_r2))
         wgrad("conv6", Slice(stage_c), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv6"), Slice(g_stage), 5, relu_mask=Slice(stage_c))
         wgrad("conv4", Slice(xin, 64, 64), Slice(g_stage, 0, 64), 5)

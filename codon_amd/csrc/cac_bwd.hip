@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void ew_add_mask_kernel(typename P::T* __restr
 // ---- host ------------------------------------------------------------------------------------------
 // ew_c8.hip: passes A and D and the elementwise helper over channel-blocked 16-bit tensors
 int cac_bwd_reduce_c8(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
-                      const float*, const float*, const float*, float*, float*, int*, int, hipStream_t);
+                      const float*, const float*, const float*, float*, float*, int*, int, hipStream_t, const float*, int*,
+                      const codon_tensor*, const codon_tensor*, int);
 int cac_bwd_apply_c8(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
                      const float*, const float*, const float*, const float*, const float*, const int*, const codon_tensor*,
                      const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int, hipStream_t);
@@ -398,7 +399,8 @@ int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_t
                    const codon_tensor* pre, const codon_tensor* pre_c, const float* ch, const float* sp,
                    const float* pools, float* g_z, float* part_gch, int* part_arg, int dtype, hipStream_t stream) {
   if (dtype != CODON_F32)
-    return cac_bwd_reduce_c8(B, H, W, g_out, g_outc, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg, dtype, stream);
+    return cac_bwd_reduce_c8(B, H, W, g_out, g_outc, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg, dtype, stream,
+                             nullptr, nullptr, nullptr, nullptr, 0);
   const long HW = (long)H * W;
   const int nt = cac_bwd_tiles(H, W);
   const bool al = al16(basep(g_out, HW, dtype), basep(g_outc, HW, dtype), basep(pre, HW, dtype),
@@ -411,6 +413,15 @@ int cac_bwd_reduce(int B, int H, int W, const codon_tensor* g_out, const codon_t
                        nt);
   });
   return check_launch("cac_bwd_reduce_kernel");
+}
+
+// 16-bit tensors only: pass A that also records the per-pixel arg-max channel and folds dL/d(out) into dL/d(inputs)
+int cac_bwd_reduce_acc(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc, const codon_tensor* pre,
+                       const codon_tensor* pre_c, const float* ch, const float* sp, const float* pools, const float* pooled,
+                       float* g_z, float* part_gch, int* part_arg, int* argch, const codon_tensor* g_in,
+                       const codon_tensor* g_in_c, int accumulate_in, int dtype, hipStream_t stream) {
+  return cac_bwd_reduce_c8(B, H, W, g_out, g_outc, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg, dtype, stream, pooled,
+                           argch, g_in, g_in_c, accumulate_in);
 }
 
 int cac_bwd_gate(int B, int H, int W, const float* part_gch, const int* part_arg, const float* ch,

@@ -45,8 +45,15 @@ int conv_chain1x1_fwd_16(const codon_conv_desc*, const void*, const void*, void*
                          const codon_tensor*, float*, float*, int, hipStream_t);
 int conv2d_gated_fwd_16(const codon_conv_desc*, const void*, const codon_tensor*, const float*, const float*, const void*,
                         void*, const codon_tensor*, hipStream_t);
+struct Conv1x1GateBwd {
+  const float* ch; const float* sp; const float* g_pooled; const float* g_pools; const int* argpix; const int* argch;
+  int fbase;
+};
 int conv1x1_bwd_16(const codon_conv_desc*, const void*, const void*, const void*, const codon_tensor*, float*, float*, size_t,
-                   int, hipStream_t);
+                   int, hipStream_t, const Conv1x1GateBwd*);
+int cac_bwd_reduce_acc(int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, const codon_tensor*,
+                       const float*, const float*, const float*, const float*, float*, float*, int*, int*, const codon_tensor*,
+                       const codon_tensor*, int, int, hipStream_t);
 int cac_fused_tiles(int, int);
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -316,7 +323,28 @@ int codon_conv1x1_bwd(const codon_conv_desc* d, const void* x, const void* gy, c
   CODON_REQUIRE(((uintptr_t)w_packed_dgrad % 16) == 0, CODON_ERR_BAD_ARG, "conv1x1_bwd: packed weights not 16-byte aligned");
   CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
                 "conv1x1_bwd: 16-bit dtypes only (dtype %d): call codon_conv2d_wgrad + codon_conv2d_fwd", d->dtype);
-  return conv1x1_bwd_16(d, x, gy, w_packed_dgrad, gx, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream);
+  return conv1x1_bwd_16(d, x, gy, w_packed_dgrad, gx, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream,
+                        nullptr);
+}
+
+int codon_conv1x1_bwd_gated(const codon_conv_desc* d, const void* x, const void* g_out, const void* w_packed_dgrad,
+                            const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
+                            const float* ch, const float* sp, const float* g_pooled, const float* g_pools,
+                            const int32_t* argpix, const int32_t* argch, int32_t fcat_base, codon_stream_t stream) {
+  CODON_REQUIRE(d && x && g_out && w_packed_dgrad && gx && gx->data && dw && workspace && ch && sp && g_pooled && g_pools &&
+                    argpix && argch,
+                CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: bad shape");
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
+                    d->y_coff + d->cout <= d->y_ctotal && gx->coff >= 0 && gx->coff + d->cin <= gx->ctotal,
+                CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: channel slice outside its buffer");
+  CODON_REQUIRE(fcat_base == 0 || fcat_base == 64, CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: fcat_base %d (0 colour, 64 depth)", fcat_base);
+  CODON_REQUIRE(((uintptr_t)w_packed_dgrad % 16) == 0, CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "conv1x1_bwd_gated: 16-bit dtypes only (dtype %d)", d->dtype);
+  const Conv1x1GateBwd gb{ch, sp, g_pooled, g_pools, argpix, argch, fcat_base};
+  return conv1x1_bwd_16(d, x, g_out, w_packed_dgrad, gx, dw, (float*)workspace, workspace_bytes, accumulate, (hipStream_t)stream,
+                        &gb);
 }
 
 int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x, const float* w_oihw, void* y,
@@ -456,6 +484,21 @@ int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const cod
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_reduce: bad shape");
   return cac_bwd_reduce(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pools, g_z, part_gch, part_arg,
                         dtype, (hipStream_t)stream);
+}
+
+int codon_cac_bwd_reduce_acc(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                             const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                             const float* ch, const float* sp, const float* pools, const float* pooled, float* g_z,
+                             float* part_gch, int32_t* part_arg, int32_t* argch, const codon_tensor* g_in,
+                             const codon_tensor* g_in_c, int32_t accumulate_in, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(dtype == CODON_BF16 || dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "cac_bwd_reduce_acc: 16-bit dtypes only (dtype %d): fp32 takes codon_cac_bwd_reduce + codon_cac_bwd_apply", dtype);
+  CODON_REQUIRE(slice_ok(g_out) && slice_ok(g_out_c) && slice_ok(pre) && slice_ok(pre_c) && slice_ok(g_in) && slice_ok(g_in_c) &&
+                    ch && sp && pools && pooled && g_z && part_gch && part_arg && argch,
+                CODON_ERR_BAD_ARG, "cac_bwd_reduce_acc: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_bwd_reduce_acc: bad shape");
+  return cac_bwd_reduce_acc(batch, height, width, g_out, g_out_c, pre, pre_c, ch, sp, pools, pooled, g_z, part_gch, part_arg,
+                            argch, g_in, g_in_c, accumulate_in, dtype, (hipStream_t)stream);
 }
 
 int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch, const int32_t* part_arg,

@@ -676,13 +676,20 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");
 }
 
+// pixel rows per wave of the plain 64-cout convs: 2 = 8 x 32 tile (4 operand fetches per 4 MFMAs), 4 = 16 x 32 tile (6 per 8)
+#ifndef CODON_F32_PSEG364
+#define CODON_F32_PSEG364 2
+#endif
+#ifndef CODON_F32_PSEG564
+#define CODON_F32_PSEG564 2
+#endif
 int conv2d_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* res,
                    hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
     case 5128128: return launch_conv<5, 128, 128, 2>(d, x, w, y, res, stream);
-    case 5064064: return launch_conv<5, 64, 64, 2>(d, x, w, y, res, stream);
-    case 3064064: return launch_conv<3, 64, 64, 2>(d, x, w, y, res, stream);
+    case 5064064: return launch_conv<5, 64, 64, CODON_F32_PSEG564>(d, x, w, y, res, stream);
+    case 3064064: return launch_conv<3, 64, 64, CODON_F32_PSEG364>(d, x, w, y, res, stream);
     case 3128064: return launch_conv<3, 128, 64, 2>(d, x, w, y, res, stream);
     case 3064128: return launch_conv<3, 64, 128, 2>(d, x, w, y, res, stream);  // dgrad of conv7
     case 1128064: return launch_conv<1, 128, 64, 2>(d, x, w, y, res, stream);

@@ -88,14 +88,29 @@ struct WgradC8Params {
   const uint4* dg_w;                   // CODON_PACK_DGRAD image of the (64,128,1,1) weight: [ks][h][128 rows][8]
   uint4* dg_y;
   long dy_img, dy_base;
+  // k = 1, DG, GB (round 4): `gy` is the block's dL/d(out) of one stream and the 1x1 conv's output gradient dL/d(pre) is
+  // formed from it WHILE THE TILE IS STAGED -- the CAC gate backward (cac_bwd_apply, one stream of it):
+  //   g_pre[c,p] = g_out[c,p] * (ch[c] * sp[p]) + g_avg[c] / HW + g_mean[p] / 128
+  //                + [p == argpix[c]] g_max[c] + [c == argch[p]] g_cmax[p]
+  // (direct term; global avg-pool broadcast; channel-mean broadcast; global max-pool routing; channel max-pool routing to
+  // the first arg-max channel in Fcat order -- CAC_module.py:43,47,81), bit for bit the value cac_bwd_apply stores
+  const float* gb_ch;                  // (B,64)
+  const float* gb_sp;                  // (B,1,H,W)
+  const float* gb_gpooled;             // (B,2,H,W): dL/d(channel max), dL/d(channel mean)
+  const float* gb_gpools;              // (B,2,128): dL/d(global avg pool), dL/d(global max pool), Fcat channel order
+  const int* gb_argpix;                // (B,128): arg-max pixel of every Fcat channel's global max pool
+  const int* gb_argch;                 // (B,H,W): first arg-max Fcat channel of every pixel (cac_bwd_reduce, ACC)
+  int gb_fbase;                        // this stream's first Fcat channel: 0 = colour, 64 = depth
+  float gb_inv_hw;
 };
 
 // TAG_CI / TAG_CO: the channel shape of the launch, carried in the kernel NAME only (the code reads p.cin / p.cout): the
 // 5x5 weight gradients of the 128 -> 128 and the 64 -> 64 convs run the same code on the same 256-workgroup grid, and
 // per-shape rows in the rocprofv3 kernel statistics / PMC tables are what the roofline accounting needs (0 = untagged)
-template <class E, int KS, bool DG = false, int TAG_CI = 0, int TAG_CO = 0>
+template <class E, int KS, bool DG = false, int TAG_CI = 0, int TAG_CO = 0, bool GB = false>
 __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void conv_wgrad_c8_kernel(const WgradC8Params p) {
   static_assert(!DG || KS == 1, "the fused input gradient exists for the 1x1 conv only");
+  static_assert(!GB || DG, "the gate backward is formed in the staging of the fused 1x1 backward");
   typedef typename E::vec8 vec8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr bool KSPLIT = (KS == 1);
@@ -247,7 +262,22 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
     }
   };
 
+  // GB: per-channel constants of this image in LDS as [plane][field][8]: ch, g_avg / HW, g_max, argpix (as int bits)
+  __shared__ float gbt[GB ? 8 * 4 * 8 : 1];
+  if constexpr (GB) {
+    if (tid < 64) {
+      const int c = tid, f = p.gb_fbase + c;
+      float* row = gbt + (c >> 3) * 32 + (c & 7);
+      row[0] = p.gb_ch[b * 64 + c];
+      row[8] = p.gb_gpools[((long)b * 2 + 0) * 128 + f] * p.gb_inv_hw;
+      row[16] = p.gb_gpools[((long)b * 2 + 1) * 128 + f];
+      row[24] = __int_as_float(p.gb_argpix[(long)b * 128 + f]);
+    }
+    __syncthreads();
+  }
   u32x4 xv[XE], gv[GE];
+  float m_sp[GB ? GE : 1], m_mean[GB ? GE : 1], m_cmax[GB ? GE : 1];   // GB: the element's pixel maps (0 outside the image)
+  int m_pix[GB ? GE : 1], m_arg[GB ? GE : 1];                           //     its pixel index (-1 outside) and arg-max channel
   auto load_tile = [&](int t) {
     const int ty = ty_begin + t / p.tiles_x, tx = t % p.tiles_x;
     const int tx0 = tx * TW, ty0 = ty * TH;
@@ -267,6 +297,15 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
       const int gy_ = ty0 + (grc[k] >> 8), gx_ = tx0 + (grc[k] & 255);
       const bool ok = grc[k] >= 0 && gy_ < H && gx_ < W;
       gv[k] = c8_ld(gr, ok ? grel[k] : C8_OOB, 0);
+      if constexpr (GB) {
+        const long q = ok ? (long)gy_ * W + gx_ : 0;          // unconditional loads from a valid address, masked below
+        const long bq = (long)b * HW + q;
+        m_sp[k] = p.gb_sp[bq];
+        m_cmax[k] = p.gb_gpooled[(long)b * 2 * HW + q];
+        m_mean[k] = p.gb_gpooled[(long)b * 2 * HW + HW + q] * (1.f / 128.f);
+        m_arg[k] = p.gb_argch[bq];
+        m_pix[k] = ok ? (int)q : -1;
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -277,7 +316,33 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
       if ((NXE % NT == 0) || tid + k * NT < NXE) *reinterpret_cast<u32x4*>(xs + xlds[k]) = xv[k];
 #pragma unroll
     for (int k = 0; k < GE; ++k)
-      if ((NGE % NT == 0) || tid + k * NT < NGE) *reinterpret_cast<u32x4*>(gs + glds[k]) = gv[k];
+      if ((NGE % NT == 0) || tid + k * NT < NGE) {
+        if constexpr (GB) {
+          const int c = (tid + k * NT) / (TW * TH);           // 8-channel plane of the element (tile independent)
+          const float* row = gbt + c * 32;
+          const float4 c0 = *reinterpret_cast<const float4*>(row), c1 = *reinterpret_cast<const float4*>(row + 4),
+                       a0 = *reinterpret_cast<const float4*>(row + 8), a1 = *reinterpret_cast<const float4*>(row + 12),
+                       x0 = *reinterpret_cast<const float4*>(row + 16), x1 = *reinterpret_cast<const float4*>(row + 20),
+                       i0 = *reinterpret_cast<const float4*>(row + 24), i1 = *reinterpret_cast<const float4*>(row + 28);
+          const float chc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          const float ga[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const float gm[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          const float ai[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+          float go[8], o[8];
+          c8_unpack<E>(gv[k], go);
+          const bool in = m_pix[k] >= 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = go[j] * (chc[j] * m_sp[k]) + ga[j] + m_mean[k];      // the expression of cac_bwd_apply_c8_kernel
+            if (m_pix[k] == __float_as_int(ai[j])) v += gm[j];
+            if (m_arg[k] == p.gb_fbase + c * 8 + j) v += m_cmax[k];
+            o[j] = in ? v : 0.f;
+          }
+          *reinterpret_cast<u32x4*>(gs + glds[k]) = c8_pack<E>(o);
+        } else {
+          *reinterpret_cast<u32x4*>(gs + glds[k]) = gv[k];
+        }
+      }
   };
 
   if constexpr (DMA) {
@@ -585,6 +650,7 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
   p.tiles_x = (d->width + 31) / 32;
   p.nbands = pl.nbands; p.nsplit = pl.nsplit;
   p.dg_w = nullptr; p.dg_y = nullptr; p.dy_img = p.dy_base = 0;
+  p.gb_ch = p.gb_sp = p.gb_gpooled = p.gb_gpools = nullptr; p.gb_argpix = p.gb_argch = nullptr; p.gb_fbase = 0; p.gb_inv_hw = 0.f;
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
   const bool f16 = d->dtype == CODON_F16;
   if (d->ksize == 5) {
@@ -608,8 +674,13 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
 
 // dL/dw AND dL/dx of a 1x1 conv 128 -> 64 whose input is a ReLU output (confuse / confuse_c / confuse_fuse,
 // CODON_x4.py:84,83,127), one pass: both are HBM-bound on the same two tensors (x = r2 128 ch, gy 64 ch)
+struct Conv1x1GateBwd {      // GB operands (see WgradC8Params); null = plain codon_conv1x1_bwd
+  const float* ch; const float* sp; const float* g_pooled; const float* g_pools; const int* argpix; const int* argch;
+  int fbase;
+};
 int conv1x1_bwd_16(const codon_conv_desc* d, const void* x, const void* gy, const void* w_dgrad, const codon_tensor* gx,
-                   float* dw, float* workspace, size_t ws_bytes, int accumulate, hipStream_t stream) {
+                   float* dw, float* workspace, size_t ws_bytes, int accumulate, hipStream_t stream,
+                   const Conv1x1GateBwd* gb) {
   Wgrad16Plan pl;
   CODON_REQUIRE(d->ksize == 1 && d->cin == 128 && d->cout == 64 && wgrad16_plan(d, &pl), CODON_ERR_UNSUPPORTED,
                 "conv1x1_bwd: k=%d cin=%d cout=%d (the fused pass exists for the 128 -> 64 1x1 convs)", d->ksize, d->cin, d->cout);
@@ -632,8 +703,19 @@ int conv1x1_bwd_16(const codon_conv_desc* d, const void* x, const void* gy, cons
   p.dg_w = (const uint4*)w_dgrad; p.dg_y = (uint4*)gx->data;
   p.dy_img = (gx->ctotal / 8) * HW; p.dy_base = (gx->coff / 8) * HW;
   const dim3 grid(pl.nchan_blocks, pl.nsplit);
-  if (d->dtype == CODON_F16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
-  else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  if (gb) {
+    p.gb_ch = gb->ch; p.gb_sp = gb->sp; p.gb_gpooled = gb->g_pooled; p.gb_gpools = gb->g_pools;
+    p.gb_argpix = gb->argpix; p.gb_argch = gb->argch; p.gb_fbase = gb->fbase;
+    p.gb_inv_hw = (float)(1.0 / (double)HW);                  // as cac_bwd_apply forms it
+    if (d->dtype == CODON_F16)
+      hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1, true, 0, 0, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+    else
+      hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1, true, 0, 0, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  } else {
+    p.gb_ch = p.gb_sp = p.gb_gpooled = p.gb_gpools = nullptr; p.gb_argpix = p.gb_argch = nullptr; p.gb_fbase = 0; p.gb_inv_hw = 0.f;
+    if (d->dtype == CODON_F16) hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8F16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
+  }
   const int st = check_launch("conv_wgrad_c8_kernel<1, dgrad>");
   if (st != CODON_OK) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, 1, pl.nsplit, accumulate, stream);

@@ -654,15 +654,159 @@ __global__ __launch_bounds__(256) void cac_bwd_reduce_c8_kernel(C8Slice g_out, C
         min(min(red_a[tid][0], red_a[tid][1]), min(red_a[tid][2], red_a[tid][3]));
 }
 
+// A, fused form (round 4, the CAC backward of a training step): the same pass ALSO (1) records, per pixel, the first
+// arg-max channel of the channel max-pool in Fcat order (colour 0..63, depth 64..127 -- what torch.max(dim=1) routes its
+// gradient to, CAC_module.py:81) and (2) folds dL/d(out) into the running dL/d(inputs) (`inputs` feeds every block:
+// CODON_x4.py:90-91,117-118).  With those two, what is left of cac_bwd_apply -- forming dL/d(pre) -- moves into the
+// staging of the 1x1 conv's backward that consumes it (conv_wgrad_c8.hip, GB) and the 12.6 GB apply pass is gone.
+// Same tiles, same per-thread pixels, same summation order as cac_bwd_reduce_c8_kernel: g_z / part_gch / part_arg are
+// bit-identical.  Six 16-byte vectors per (plane, pixel): the 8-pixel unroll of the plain pass would need 351 VGPRs (one
+// wave per SIMD), so the pixels are walked four at a time and the per-pixel state lives in LDS.
+template <class E>
+__global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
+    C8Slice g_out, C8Slice g_outc, C8Slice pre, C8Slice pre_c, C8Slice g_in, C8Slice g_in_c, const float* __restrict__ ch,
+    const float* __restrict__ sp, const float* __restrict__ pools, const float* __restrict__ pooled, float* __restrict__ g_z,
+    float* __restrict__ part_gch, int* __restrict__ part_arg, int* __restrict__ argch, long HW, int ntiles, int accumulate_in) {
+  constexpr int KH = 4;                               // pixels in flight per thread
+  __shared__ float red_s[64][4];
+  __shared__ int red_a[128][4];
+  __shared__ float st_sp[EW_NP][256], st_gsp[EW_NP][256], st_pmx[EW_NP][256];
+  __shared__ unsigned st_acd[EW_NP][256];             // (first colour channel | first depth channel << 8) equal to the channel max
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const long tile0 = (long)tile * EW_TILE;
+  const unsigned HW16 = 16u * (unsigned)HW;
+#pragma unroll
+  for (int k = 0; k < EW_NP; ++k) {
+    const long q = tile0 + k * 256 + tid;
+    const bool in = q < HW;
+    st_sp[k][tid] = in ? sp[(long)b * HW + q] : 0.f;
+    st_gsp[k][tid] = 0.f;
+    st_pmx[k][tid] = in ? pooled[(long)b * 2 * HW + q] : 0.f;
+    st_acd[k][tid] = 0xFFFFu;
+  }
+  const float* mx = pools + ((long)b * 2 + 1) * 128;
+  const __amdgpu_buffer_rsrc_t r_go = c8_rsrc(g_out, b, 8, HW16), r_gc = c8_rsrc(g_outc, b, 8, HW16),
+                               r_p = c8_rsrc(pre, b, 8, HW16), r_pc = c8_rsrc(pre_c, b, 8, HW16),
+                               r_gi = c8_rsrc(g_in, b, 8, HW16), r_gic = c8_rsrc(g_in_c, b, 8, HW16);
+#pragma unroll 1
+  for (int pl = 0; pl < 8; ++pl) {
+    const unsigned so = (unsigned)pl * HW16;
+    float chc[8], mxc[8], mxd[8], s8[8];
+    int ad[8], ac[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      chc[j] = ch[b * 64 + pl * 8 + j];
+      mxc[j] = mx[pl * 8 + j];            // Fcat order: colour c, depth 64 + c
+      mxd[j] = mx[64 + pl * 8 + j];
+      s8[j] = 0.f; ad[j] = INT_MAX; ac[j] = INT_MAX;
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < EW_NP; k0 += KH) {
+      u32x4 qgo[KH], qgc[KH], qp[KH], qpc[KH], qi[KH], qic[KH];
+      unsigned vo[KH];
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) {
+        const long q = tile0 + (k0 + kk) * 256 + tid;
+        vo[kk] = q < HW ? 16u * (unsigned)q : C8_OOB;
+        qgo[kk] = c8_ld(r_go, vo[kk], so);
+        qgc[kk] = c8_ld(r_gc, vo[kk], so);
+        qp[kk] = c8_ld(r_p, vo[kk], so);
+        qpc[kk] = c8_ld(r_pc, vo[kk], so);
+        if (accumulate_in) { qi[kk] = c8_ld(r_gi, vo[kk], so); qic[kk] = c8_ld(r_gic, vo[kk], so); }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) {
+        const int k = k0 + kk;
+        const int pix = (int)tile0 + k * 256 + tid;
+        const bool in = vo[kk] != C8_OOB;
+        const float spv = st_sp[k][tid], pmx = st_pmx[k][tid];
+        float gsp = st_gsp[k][tid];
+        unsigned acd = st_acd[k][tid];
+        float go[8], gc[8], p[8], pc[8];
+        c8_unpack<E>(qgo[kk], go);
+        c8_unpack<E>(qgc[kk], gc);
+        c8_unpack<E>(qp[kk], p);
+        c8_unpack<E>(qpc[kk], pc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gg = go[j] * p[j] + gc[j] * pc[j];
+          s8[j] = fmaf(gg, spv, s8[j]);
+          gsp = fmaf(gg, chc[j], gsp);
+          if (in && p[j] == mxd[j]) ad[j] = min(ad[j], pix);
+          if (in && pc[j] == mxc[j]) ac[j] = min(ac[j], pix);
+          // planes are walked in ascending channel order: the first match of each stream is kept
+          if (pc[j] == pmx && (acd & 0xFFu) == 0xFFu) acd = (acd & 0xFF00u) | (unsigned)(pl * 8 + j);
+          if (p[j] == pmx && (acd >> 8) == 0xFFu) acd = (acd & 0xFFu) | ((unsigned)(pl * 8 + j) << 8);
+        }
+        st_gsp[k][tid] = gsp;
+        st_acd[k][tid] = acd;
+        if (accumulate_in) {               // g_inputs (+)= g_out, the arithmetic of cac_bwd_apply_c8_kernel
+          float gi[8], gic[8];
+          c8_unpack<E>(qi[kk], gi);
+          c8_unpack<E>(qic[kk], gic);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { gi[j] = gi[j] + go[j]; gic[j] = gic[j] + gc[j]; }
+          c8_st(c8_pack<E>(gi), r_gi, vo[kk], so);
+          c8_st(c8_pack<E>(gic), r_gic, vo[kk], so);
+        } else {
+          c8_st(qgo[kk], r_gi, vo[kk], so);
+          c8_st(qgc[kk], r_gic, vo[kk], so);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = c8_wsum(s8[j]);
+      const int a_d = c8_wmin(ad[j]), a_c = c8_wmin(ac[j]);
+      if (lane == 0) { red_s[pl * 8 + j][wave] = s; red_a[pl * 8 + j][wave] = a_c; red_a[64 + pl * 8 + j][wave] = a_d; }
+    }
+  }
+  // dL/dz = dL/dsp * sp * (1 - sp); the pixel's arg-max channel
+#pragma unroll
+  for (int k = 0; k < EW_NP; ++k) {
+    const long q = tile0 + k * 256 + tid;
+    if (q < HW) {
+      const float spv = st_sp[k][tid];
+      g_z[(long)b * HW + q] = st_gsp[k][tid] * spv * (1.f - spv);
+      const unsigned acd = st_acd[k][tid];
+      const int ac_ = (int)(acd & 0xFFu), ad_ = (int)(acd >> 8);
+      argch[(long)b * HW + q] = ac_ != 255 ? ac_ : (ad_ != 255 ? 64 + ad_ : 255);
+    }
+  }
+  __syncthreads();
+  if (tid < 64)
+    part_gch[((long)b * ntiles + tile) * 64 + tid] = (red_s[tid][0] + red_s[tid][1]) + (red_s[tid][2] + red_s[tid][3]);
+  if (tid < 128)
+    part_arg[((long)b * ntiles + tile) * 128 + tid] =
+        min(min(red_a[tid][0], red_a[tid][1]), min(red_a[tid][2], red_a[tid][3]));
+}
+
 int cac_bwd_reduce_c8(int B, int H, int W, const codon_tensor* g_out, const codon_tensor* g_outc, const codon_tensor* pre,
                       const codon_tensor* pre_c, const float* ch, const float* sp, const float* pools, float* g_z,
-                      float* part_gch, int* part_arg, int dtype, hipStream_t stream) {
+                      float* part_gch, int* part_arg, int dtype, hipStream_t stream, const float* pooled, int* argch,
+                      const codon_tensor* g_in, const codon_tensor* g_in_c, int accumulate_in) {
   const long HW = (long)H * W;
   const int nt = (int)((HW + EW_TILE - 1) / EW_TILE);
   for (const codon_tensor* t : {g_out, g_outc, pre, pre_c})
     CODON_REQUIRE(c8_slice_ok(t->ctotal, t->coff, 64), CODON_ERR_BAD_ARG,
                   "cac_bwd_reduce: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
   CODON_REQUIRE(HW * 2 * 64 < (long)C8_OOB, CODON_ERR_UNSUPPORTED, "cac_bwd_reduce: image too large for 32-bit buffer offsets");
+  if (argch != nullptr) {
+    CODON_REQUIRE(pooled && g_in && g_in_c && c8_slice_ok(g_in->ctotal, g_in->coff, 64) &&
+                      c8_slice_ok(g_in_c->ctotal, g_in_c->coff, 64),
+                  CODON_ERR_BAD_ARG, "cac_bwd_reduce_acc: pooled / g_in / g_in_c");
+    if (dtype == CODON_F16)
+      hipLaunchKernelGGL(cac_bwd_reduce_acc_c8_kernel<C8F16>, dim3(nt, B), dim3(256), 0, stream, c8_mk(g_out, HW),
+                         c8_mk(g_outc, HW), c8_mk(pre, HW), c8_mk(pre_c, HW), c8_mk(g_in, HW), c8_mk(g_in_c, HW), ch, sp, pools,
+                         pooled, g_z, part_gch, part_arg, argch, HW, nt, accumulate_in);
+    else
+      hipLaunchKernelGGL(cac_bwd_reduce_acc_c8_kernel<C8Bf16>, dim3(nt, B), dim3(256), 0, stream, c8_mk(g_out, HW),
+                         c8_mk(g_outc, HW), c8_mk(pre, HW), c8_mk(pre_c, HW), c8_mk(g_in, HW), c8_mk(g_in_c, HW), ch, sp, pools,
+                         pooled, g_z, part_gch, part_arg, argch, HW, nt, accumulate_in);
+    return check_launch("cac_bwd_reduce_acc_c8_kernel");
+  }
   if (dtype == CODON_F16)
     hipLaunchKernelGGL(cac_bwd_reduce_c8_kernel<C8F16>, dim3(nt, B), dim3(256), 0, stream, c8_mk(g_out, HW), c8_mk(g_outc, HW),
                        c8_mk(pre, HW), c8_mk(pre_c, HW), ch, sp, pools, g_z, part_gch, part_arg, HW, nt);

@@ -459,3 +459,68 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
                                         _ptr(argpix), C.byref(t[4]), C.byref(t[5]), C.byref(t[6]), C.byref(t[7]),
                                         1 if accumulate_in else 0, _dt(pre.buf), st), "cac_bwd_apply")
     return dw1, db1, dw2, db2, dws
+
+
+def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
+                       g_in: Slice, g_in_c: Slice, accumulate_in: bool):
+    """16-bit tensors, training: the CAC gate backward WITHOUT the apply pass.  Pass A also records every pixel's arg-max
+    channel and folds g_out into g_in (codon_cac_bwd_reduce_acc); dL/d(pre) is not materialised -- conv1x1_bwd_gated forms
+    it from g_out while staging.  Returns (dw1, db1, dw2, db2, dws, gate) with gate = the operands conv1x1_bwd_gated needs."""
+    lib = L.load()
+    dev = _dev(g_out.buf, g_out_c.buf, pre.buf, pre_c.buf, ch, sp, pooled, pools, w1, b1, w2, ws, g_in.buf, g_in_c.buf)
+    assert is_c8(pre.buf.dtype)
+    B, H, W = _bhw(pre.buf)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    nt = lib.codon_cac_bwd_tiles(H, W)
+    nsb = lib.codon_cac_bwd_spatial_blocks(B, H, W)
+    g_z = torch.empty((B, 1, H, W), **f32)
+    part_gch = torch.empty((B, nt, 64), **f32)
+    part_arg = torch.empty((B, nt, 128), **i32)
+    argch = torch.empty((B, H, W), **i32)
+    g_pools = torch.empty((B, 2, 128), **f32)
+    argpix = torch.empty((B, 128), **i32)
+    part_param = torch.empty((B, 1608), **f32)
+    dw1, db1 = torch.empty((8, 128), **f32), torch.empty((8,), **f32)
+    dw2, db2 = torch.empty((64, 8), **f32), torch.empty((64,), **f32)
+    g_pooled = torch.empty((B, 2, H, W), **f32)
+    part_w = torch.empty((nsb, 50), **f32)
+    dws = torch.empty((1, 2, 5, 5), **f32)
+    t = [s_.ct() for s_ in (g_out, g_out_c, pre, pre_c, g_in, g_in_c)]
+    st = _stream(dev)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_bwd_reduce_acc(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]), _ptr(ch),
+                                             _ptr(sp), _ptr(pools), _ptr(pooled), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
+                                             _ptr(argch), C.byref(t[4]), C.byref(t[5]), 1 if accumulate_in else 0,
+                                             _dt(pre.buf), st), "cac_bwd_reduce_acc")
+        L.check(lib.codon_cac_bwd_gate(B, H, W, _ptr(part_gch), _ptr(part_arg), _ptr(ch), _ptr(pools), _ptr(w1),
+                                       _ptr(b1), _ptr(w2), _ptr(g_pools), _ptr(argpix), _ptr(part_param), _ptr(dw1),
+                                       _ptr(db1), _ptr(dw2), _ptr(db2), st), "cac_bwd_gate")
+        L.check(lib.codon_cac_bwd_spatial(B, H, W, _ptr(g_z), _ptr(pooled), _ptr(ws), _ptr(g_pooled), _ptr(part_w),
+                                          _ptr(dws), st), "cac_bwd_spatial")
+    gate = dict(ch=ch, sp=sp, g_pooled=g_pooled, g_pools=g_pools, argpix=argpix, argch=argch)
+    return dw1, db1, dw2, db2, dws, gate
+
+
+def conv1x1_bwd_gated(x: Slice, g_out: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: torch.Tensor, gate: dict,
+                      fcat_base: int, accumulate: bool = False):
+    """conv1x1_bwd whose output gradient dL/d(pre) is formed from the block's dL/d(out) `g_out` (one stream's 64 channels)
+    while it is staged -- see cac_backward_fused.  fcat_base: 0 = colour stream (confuse_c), 64 = depth stream (confuse)."""
+    lib = L.load()
+    dev = _dev(x.buf, g_out.buf, w_packed_dgrad, gx.buf, dw, *gate.values())
+    B, H, W = _bhw(x.buf)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (g_out.c, x.c, 1, 1) and gx.c == x.c and _bhw(gx.buf) == (B, H, W)
+    assert gx.buf.dtype == x.buf.dtype == g_out.buf.dtype and gx.buf.data_ptr() not in (x.buf.data_ptr(), g_out.buf.data_ptr())
+    assert tuple(gate["argch"].shape) == (B, H, W) and gate["argch"].dtype == torch.int32
+    d = L.ConvDesc(B, H, W, x.c, g_out.c, 1, x.ctotal, x.coff, g_out.ctotal, g_out.coff, 0, 0, 0, _dt(x.buf))
+    nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(f"codon_amd: no wgrad kernel for k=1 cin={x.c} cout={g_out.c}")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    gt = gx.ct()
+    with torch.cuda.device(dev):
+        L.check(lib.codon_conv1x1_bwd_gated(C.byref(d), _ptr(x.buf), _ptr(g_out.buf), _ptr(w_packed_dgrad), C.byref(gt),
+                                            _ptr(dw), _ptr(ws), nbytes, 1 if accumulate else 0, _ptr(gate["ch"]),
+                                            _ptr(gate["sp"]), _ptr(gate["g_pooled"]), _ptr(gate["g_pools"]),
+                                            _ptr(gate["argpix"]), _ptr(gate["argch"]), fcat_base, _stream(dev)),
+                "conv1x1_bwd_gated")

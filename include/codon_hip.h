@@ -176,6 +176,16 @@ int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, 
 int codon_conv1x1_bwd(const codon_conv_desc* d, const void* x, const void* gy, const void* w_packed_dgrad,
                       const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
                       codon_stream_t stream);
+/* Same pass with the CAC gate backward formed while the output-gradient tile is staged (16-bit tensors, training): g_out is
+ * ONE stream's half of the block's dL/d(out) (the 64-channel slice d->y_*), and the 1x1 conv's output gradient is
+ *   dL/d(pre)[c,p] = g_out[c,p] * ch[c] * sp[p] + g_pools[0][f]/HW + g_pooled[1][p]/128
+ *                    + [p == argpix[f]] g_pools[1][f] + [f == argch[p]] g_pooled[0][p],   f = fcat_base + c
+ * -- what codon_cac_bwd_apply would store as g_pre, bit for bit (autograd of CODON_x4.py:85-91, CAC_module.py:38-94).
+ * argch: (B,H,W) int32 from codon_cac_bwd_reduce_acc; fcat_base: 0 = colour stream, 64 = depth stream. */
+int codon_conv1x1_bwd_gated(const codon_conv_desc* d, const void* x, const void* g_out, const void* w_packed_dgrad,
+                            const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
+                            const float* ch, const float* sp, const float* g_pooled, const float* g_pools,
+                            const int32_t* argpix, const int32_t* argch, int32_t fcat_base, codon_stream_t stream);
 
 /* ---- stem / head stencils (HBM-bound) ----------------------------------------------------
  * stem: y[:, y_coff:y_coff+64] = relu(conv3x3_{1->64}(x))        CODON_x4.py:68,71
@@ -269,6 +279,15 @@ int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const cod
                          const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
                          const float* ch, const float* sp, const float* pools, float* g_z,
                          float* part_gch, int32_t* part_arg, int32_t dtype, codon_stream_t stream);
+/* 16-bit tensors: pass A that ALSO writes argch (B,H,W) int32 = the first arg-max channel of every pixel's channel max-pool
+ * in Fcat order (255 if none; pooled = the forward's (B,2,H,W) {max, mean} map) and folds dL/d(out) into the running
+ * dL/d(inputs): g_in (+)= g_out, g_in_c (+)= g_out_c (accumulate_in = 0: plain copy).  With codon_conv1x1_bwd_gated this
+ * replaces codon_cac_bwd_apply in a training step. */
+int codon_cac_bwd_reduce_acc(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
+                             const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
+                             const float* ch, const float* sp, const float* pools, const float* pooled, float* g_z,
+                             float* part_gch, int32_t* part_arg, int32_t* argch, const codon_tensor* g_in,
+                             const codon_tensor* g_in_c, int32_t accumulate_in, int32_t dtype, codon_stream_t stream);
 int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float* part_gch,
                        const int32_t* part_arg, const float* ch, const float* pools, const float* w1,
                        const float* b1, const float* w2, float* g_pools, int32_t* argpix,

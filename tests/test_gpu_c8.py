@@ -365,6 +365,18 @@ def test_training_schedules_agree_bit_for_bit():
         A.FUSED_1X1_BWD = oldf
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], g2[n]), n
+    # ... and the CAC backward with / without its apply pass (round 4: cac_backward_fused + conv1x1_bwd_gated)
+    oldc = A.FUSED_CAC_BWD
+    try:
+        A.FUSED_CAC_BWD = not oldc
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g3 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.FUSED_CAC_BWD = oldc
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], g3[n]), n
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -396,6 +408,62 @@ def test_conv1x1_bwd_equals_wgrad_plus_masked_dgrad(shape, dtype):
         assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 192:]).all()
     ref = torch.einsum("bohw,oi->bihw", ops.to_nchw(g)[:, 64:].float(), w[:, :, 0, 0]) * (ops.to_nchw(x)[:, 64:] > 0)
     assert rel_rmse(ops.to_nchw(gx0).float().cpu(), ref.cpu()) < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 50, 70), (2, 64, 96)])
+@pytest.mark.parametrize("accumulate_in", [False, True])
+def test_fused_cac_backward_equals_the_apply_pass(shape, dtype, accumulate_in):
+    """Round 4: the CAC gate backward without its apply pass.  codon_cac_bwd_reduce_acc (pass A that also records every
+    pixel's arg-max channel and folds dL/d(out) into dL/d(inputs)) + codon_conv1x1_bwd_gated (dL/d(pre) formed from dL/d(out)
+    while the 1x1 backward stages it) against the four-kernel form + codon_conv1x1_bwd on the g_pre it stores: dL/d(inputs),
+    all five parameter gradients, the 1x1 convs' dW and the ReLU-masked dL/d(r2) of BOTH streams bit for bit -- values are
+    16-bit, so exact ties in the channel max (routing to the first Fcat channel) and in the global max pools are common."""
+    from codon_amd import ops
+    from codon_amd import _lib as L
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    # coarse values: many exact ties across channels and pixels
+    q = lambda seed, s=1.0: ops.from_nchw(((_rand((B, 128, H, W), seed, s) * 4).round() / 4).to(dev), dtype)
+    g_oc, pre2, g_in0 = q(1, 0.5), q(2), q(3, 0.5)
+    r2 = {0: ops.from_nchw(torch.relu(_rand((B, 128, H, W), 4)).to(dev), dtype),
+          64: ops.from_nchw(torch.relu(_rand((B, 128, H, W), 5)).to(dev), dtype)}
+    w1, b1, w2 = _rand((8, 128), 7, 0.1).to(dev), _rand((8,), 8, 0.1).to(dev), _rand((64, 8), 9, 0.3).to(dev)
+    b2, ws = _rand((64,), 10, 0.1).to(dev), _rand((1, 2, 5, 5), 11, 0.2).to(dev)
+    wc = {0: ops.packed_weight(_rand((64, 128, 1, 1), 12, 0.1).to(dev), mode=L.PACK_DGRAD, dtype=dtype),
+          64: ops.packed_weight(_rand((64, 128, 1, 1), 13, 0.1).to(dev), mode=L.PACK_DGRAD, dtype=dtype)}
+    nt = ops.cac_stats_tiles(H, W)
+    pooled, partials = torch.empty((B, 2, H, W), device=dev), torch.empty((B, nt, 128, 2), device=dev)
+    ch, sp, pools = torch.empty((B, 64), device=dev), torch.empty((B, 1, H, W), device=dev), torch.empty((B, 2, 128), device=dev)
+    ops.cac_stats(Slice(pre2, 64, 64), Slice(pre2, 0, 64), pooled, partials)
+    ops.cac_gate(B, H, W, partials, w1, b1, w2, b2, ch, pools)
+    ops.cac_spatial(pooled, ws, sp)
+    # the four-kernel form: [depth | colour] halves, depth = Fcat channels 64..127
+    gi0, gp0 = g_in0.clone(), ops.new_act(B, 128, H, W, dtype, dev)
+    outs0 = ops.cac_backward(Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), ch, sp, pooled,
+                             pools, w1, b1, w2, ws, Slice(gp0, 0, 64), Slice(gp0, 64, 64), Slice(gi0, 0, 64),
+                             Slice(gi0, 64, 64), accumulate_in=accumulate_in)
+    gi1 = g_in0.clone()
+    *outs1, gate = ops.cac_backward_fused(Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), ch,
+                                          sp, pooled, pools, w1, b1, w2, ws, Slice(gi1, 0, 64), Slice(gi1, 64, 64),
+                                          accumulate_in=accumulate_in)
+    assert torch.equal(gi1, gi0)
+    for a, b in zip(outs1, outs0):
+        assert torch.equal(a, b)
+    # the per-pixel arg-max channel against torch.max over Fcat = cat(colour, depth) (first maximum wins)
+    F2 = ops.to_nchw(pre2).float()
+    Fcat = torch.cat((F2[:, 64:], F2[:, :64]), 1)
+    assert torch.equal(gate["argch"].long(), Fcat.max(dim=1).indices)
+    for fbase, coff in ((64, 0), (0, 64)):                # depth stream: g_oc / g_pre channels 0..63; colour: 64..127
+        for acc in (False, True):
+            dw0 = torch.full((64, 128, 1, 1), 0.25, device=dev)
+            dw1 = dw0.clone()
+            gx0, gx1 = ops.new_act(B, 128, H, W, dtype, dev), ops.new_act(B, 128, H, W, dtype, dev)
+            ops.conv1x1_bwd(Slice(r2[fbase]), Slice(gp0, coff, 64), wc[fbase], Slice(gx0), dw0, accumulate=acc)
+            ops.conv1x1_bwd_gated(Slice(r2[fbase]), Slice(g_oc, coff, 64), wc[fbase], Slice(gx1), dw1, gate, fbase, accumulate=acc)
+            assert torch.equal(dw1, dw0), (fbase, acc)
+            assert torch.equal(gx1, gx0), (fbase, acc)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
