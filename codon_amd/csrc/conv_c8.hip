@@ -194,8 +194,10 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
       if constexpr (DMA) {                                                              \
         const unsigned vo_ = xoff[k];   /* passed as xoff[k] the host pass drops the kernel's stub (hipcc 7.2) */ \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(lds + (buf_) * XSP + k * NT + wave_u * 64), 16, \
-                                                 vo_, so_, 0, 0);                       \
+        /* a wave whose 64 slots all lie past the tile (last round) issues nothing: the slots are never read */ \
+        if (XS % NT == 0 || k < XE - 1 || k * NT + wave_u * 64 < XS)                    \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(lds + (buf_) * XSP + k * NT + wave_u * 64), 16, \
+                                                   vo_, so_, 0, 0);                     \
       } else {                                                                          \
         xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_);                                     \
         if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, xoff[k], so_);                 \
@@ -228,8 +230,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
       if constexpr (DMA) {                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + k * NT + wave_u * 64), 16, \
-                                                 k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16), 0, 0); \
+        if (WS % NT == 0 || k < WE - 1 || k * NT + wave_u * 64 < WS)                    \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + k * NT + wave_u * 64), 16, \
+                                                   k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16), 0, 0); \
       } else {                                                                          \
         wr[k] = c8_ld(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16)); \
       }                                                                                 \

@@ -243,8 +243,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 4);                  \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                               \
       if constexpr (DMA) {                                                         \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + (k * NT + wave_u * 64) * 4), \
-                                                 16, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0, 0); \
+        /* a wave whose 64 float4 slots all lie past the stage (last round) issues nothing: never read */ \
+        if (W4 % NT == 0 || k < WE - 1 || k * NT + wave_u * 64 < W4)               \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + (k * NT + wave_u * 64) * 4), \
+                                                   16, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0, 0); \
       } else {                                                                     \
         const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, k == WE - 1 ? wvo_last : wvo, so_ + k * (NT * 16u), 0); \
         wr[k] = *reinterpret_cast<const float4*>(&v_);                             \
