@@ -143,7 +143,16 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
   constexpr int XE = DMA ? 1 : (NXE + NT - 1) / NT, GE = DMA ? 1 : (NGE + NT - 1) / NT;
   constexpr int NK = TH * (TW / 16);
 
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (XBYTES + GBYTES)];
+  // k = 5: THREE tile buffers -- the DMA of tile t+3 is issued behind tile t's MFMAs and has two tile times (not one) to
+  // land; the wait in front of the publishing barrier leaves the youngest tile's pieces in flight (counted vmcnt: every
+  // wave issues exactly PPW pieces per tile, loads return in order).  110 KB of LDS: the kernel runs one workgroup per
+  // CU anyway (12 waves).  -DCODON_WC8_NBUF5=2 restores the double buffer (A/B).
+#ifndef CODON_WC8_NBUF5
+#define CODON_WC8_NBUF5 3
+#endif
+  constexpr int NBUF = (DMA && KS == 5) ? CODON_WC8_NBUF5 : 2;
+  static_assert(NBUF == 2 || (NBUF == 3 && NPIECE % NWV == 0 && PPW <= 15), "counted vmcnt needs the same piece count in every wave");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * (XBYTES + GBYTES)];
   typedef __attribute__((address_space(3))) void lds_void;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -374,10 +383,13 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
         __syncthreads();
         read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds0 + a_lane, lds0 + b_lane);
         if (ntile > 1) stage_tile(1, 1);
+        if (NBUF == 3 && ntile > 2) stage_tile(2, 2);
       }
+      int bi = 0;                                // buffer of tile t: t % NBUF
 #pragma unroll 1
       for (int t = 0; t < ntile; ++t) {
-        const unsigned cb = lds0 + (t & 1) * (XBYTES + GBYTES), nb = lds0 + ((t + 1) & 1) * (XBYTES + GBYTES);
+        const int bn = bi + 1 == NBUF ? 0 : bi + 1;
+        const unsigned cb = lds0 + bi * (XBYTES + GBYTES), nb = lds0 + bn * (XBYTES + GBYTES);
         static_for_wc8<NK>([&](auto kc) {
           constexpr int ks = decltype(kc)::value;
           constexpr int cur = ks & 1;
@@ -386,8 +398,10 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
             wc8_wait_lgkm<2 + NB>(a2[cur], wb[cur]);
           } else {
             wc8_wait_lgkm<0>(a2[cur], wb[cur]);
-            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this wave's pieces of tile t+1 have landed
-            __syncthreads();                     // ... everyone's have, and everyone is done reading buffer t & 1
+            // this wave's pieces of tile t+1 have landed (three buffers: tile t+2's PPW pieces may stay in flight)
+            if (NBUF == 3 && t + 2 < ntile) __builtin_amdgcn_s_waitcnt(0x0070 | PPW);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            __syncthreads();                     // ... everyone's have, and everyone is done reading tile t's buffer
             if (t + 1 < ntile) read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{}, nb + a_lane, nb + b_lane);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -420,9 +434,10 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
           }
           if constexpr (ks + 1 == NK) {            // behind the MFMAs: its address arithmetic runs beside them
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntile) stage_tile(t + 2, t & 1);
+            if (t + NBUF < ntile) stage_tile(t + NBUF, bi);
           }
         });
+        bi = bn;
       }
     };
     if constexpr (BAL) {

@@ -300,7 +300,7 @@ class _CODONBase(nn.Module):
 
     def _guard(self, dev):
         """One checksum launch per forward over the 17 MFMA conv weights (see _WeightGuard)."""
-        if not WEIGHT_GUARD:
+        if not WEIGHT_GUARD or self.__dict__.get("_no_guard", False):
             return
         g = self.__dict__.get("_wguard")
         if g is None:
@@ -342,6 +342,9 @@ class _CODONBase(nn.Module):
         r = super()._replicate_for_data_parallel()
         r._pack_cache = {}
         r._wguard = None
+        # nn.DataParallel builds fresh replicas (fresh weight copies, empty pack cache) for EVERY forward: nothing can be
+        # stale in one, and a guard per call would cost a pinned allocation each time
+        r._no_guard = True
         return r
 
     # -- forward ---------------------------------------------------------------------------

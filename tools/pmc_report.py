@@ -83,14 +83,17 @@ def alg_bytes(name, P, es, mode):
             emit = k == 5
             return (((3 if emit else 2) * ci + co) * 4 * P, "gated staging" + (" + emitted gated input" if emit else ""))
         return ((ci + co) * 4 * P, "forward conv")
-    m = re.match(r"conv_wgrad_c8_kernel<C8\w+, (\d)(?:, (true|false))?(?:, (\d+), (\d+))?>", name)
+    m = re.match(r"conv_wgrad_c8_kernel<C8\w+, (\d)(?:, (true|false))?(?:, (\d+), (\d+))?(?:, (true|false))?>", name)
     if m:
-        k, dg = int(m.group(1)), m.group(2) == "true"
-        if k == 1:
-            return ((128 + 64 + (128 if dg else 0)) * es * P, "1x1 128->64: x, gy in" + (", masked gx out" if dg else ""))
-        if m.group(3):
+        k, dg, gb = int(m.group(1)), m.group(2) == "true", m.group(5) == "true"
+        if k == 1:       # GB: gy is the block's dL/d(out), dL/d(pre) formed while staging: + four fp32 / int32 maps per pixel
+            return ((128 + 64 + (128 if dg else 0)) * es * P + (16 * P if gb else 0),
+                    "1x1 128->64: x, gy in" + (", masked gx out" if dg else "") + (", gate-backward maps in" if gb else ""))
+        if m.group(3) and int(m.group(3)) > 0:
             ci, co = int(m.group(3)), int(m.group(4))
             return ((ci + co) * es * P, f"wgrad {ci}->{co}: x, gy in")
+        if k == 3 and train:
+            return ((64 + 64) * es * P, "wgrad 3x3 (every 3x3 conv of the net but conv7 is 64->64; conv7: 1 launch in 17)")
         return (None, "mixed")                         # one instantiation serves several channel shapes
     table = {"cac_apply_c8_kernel": 6 * 64 * es * P + 4 * P, "cac_stats_c8_kernel": 128 * es * P + 8 * P,
              "cac_apply_kernel": 6 * 64 * 4 * P + 4 * P, "cac_stats_kernel": 128 * 4 * P + 8 * P,
@@ -99,7 +102,10 @@ def alg_bytes(name, P, es, mode):
              "conv1x1_c8_kernel<C8Bf16, 64, 128>": (64 + 128 + 128) * es * P,
              # per block: g_out, pre in; g_pre, g_in out (2 x 64 channels each) = 8 x 64; blocks 3..0 also READ the running
              # g_in (accumulate): 10 x 64 -- a training step launches 1 + 4 of them: 9.6 x 64 on average
-             "cac_bwd_apply_c8_kernel": 9.6 * 64 * es * P, "cac_bwd_reduce_c8_kernel": 4 * 64 * es * P}
+             "cac_bwd_apply_c8_kernel": 9.6 * 64 * es * P, "cac_bwd_reduce_c8_kernel": 4 * 64 * es * P,
+             # fused pass A: g_out, pre in (4 x 64), g_in out (2 x 64), g_in in on 4 of the 5 launches of a step (1.6 x 64),
+             # + sp, pooled max in, g_z, argch out (4 B per pixel each)
+             "cac_bwd_reduce_acc_c8_kernel": 7.6 * 64 * es * P + 16 * P}
     for k, v in table.items():
         if name.startswith(k):
             return (v, "single role")
