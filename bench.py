@@ -277,7 +277,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_c8_kernel<5>" if dtype == "bf16" else "conv_wgrad_f32_t16_kernel<5>") +
                                    " 128->128 + its fixed-order reduce (dW of conv3 / conv6 / conv10)",
                          "achieved": wach, "peak": peak, "unit": "TFLOP/s", "frac": wach / peak,
-                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5, false, 128, 128>", B, H, W,
+                         "traffic": pmc_traffic("conv_wgrad_c8_kernel<C8Bf16, 5, false, 128, 128", B, H, W,
                                                 "r*_bf16_train_b32_480x640_pmc.json") if dtype == "bf16" else None,
                          "traffic_note": "PMC bytes per launch of the 128->128 launches only (the kernel name carries the shape)",
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
