@@ -30,6 +30,11 @@ class GraphedCODON:
         # they were packed from, so a replay after a weight update is refused instead of silently stale
         self._packed_refs = [v[1] for v in self.model._pack_cache.values()]
         self._tags = self._weight_tags()
+        # ... and of the weight guard's workspace, reference slot and host-visible flag word (model._WeightGuard): the captured
+        # checksum launch compares on every replay and reports into THIS flag word, whatever the model's guard does later
+        g = getattr(self.model, "_wguard", None)
+        self._guard_refs = (g.flag, list(g.states.values())) if g is not None else None
+        self._flag_np = g.flag_np if g is not None else None
 
     def _weight_tags(self):
         return [(p.data_ptr(), p._version) for p in self.model.parameters()]
@@ -40,8 +45,12 @@ class GraphedCODON:
         such weights sets the guard's host-visible flag; with synchronize=True every replay enqueued so far is judged."""
         if self._weight_tags() != self._tags:
             return True
+        if synchronize:
+            torch.cuda.synchronize(self.x.device)
+        if self._flag_np is not None and bool(self._flag_np[0]):
+            return True
         try:
-            self.model.check_packed(synchronize=synchronize)
+            self.model.check_packed(synchronize=False)
         except RuntimeError:
             return True
         return False

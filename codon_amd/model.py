@@ -78,15 +78,22 @@ class _WeightGuard:
         self.flag_np = None
         self.states = {}           # (thread id, stream handle) -> [tag, workspace, desc, tensor whose last word is the reference]
         self.disabled = False
+        self._retired = []         # flag words / workspaces of earlier epochs (see reset)
 
     def tripped(self) -> bool:
         return self.flag_np is not None and bool(self.flag_np[0])
 
     def reset(self):
+        """Forget the recorded checksums and the tripped state.  A checksum launch of the stale forward may still be in
+        flight and a captured hipGraph may still hold the addresses: the old flag word and workspaces are retired (kept
+        alive, never reused), not cleared or freed -- a late store cannot trip the NEW flag, a replay cannot write into
+        memory someone else now owns."""
         self.tag = None
-        self.states.clear()
-        if self.flag_np is not None:
-            self.flag_np[0] = 0
+        self._retired.append((self.flag, list(self.states.values())))
+        del self._retired[:-8]                 # bounded: each entry is a few KB
+        self.states = {}
+        self.flag = None
+        self.flag_np = None
 
     def run(self, model, dev):
         import ctypes as C

@@ -488,6 +488,14 @@ def test_packed_weight_verification_catches_data_writes(monkeypatch):
         o3 = m(x, x)
         m.check_packed()
         assert not torch.equal(o3, o2)
+        # the remedy applied WITHOUT a synchronisation in between: the stale forward's checksum launch may still be in
+        # flight when invalidate_packed() runs -- its late store goes to the retired flag word, not the new one
+        m.conv3.weight.data.mul_(0.5)
+        m(x, x)
+        m.invalidate_packed()
+        for _ in range(3):
+            m(x, x)
+        m.check_packed()
         # the debug switch: same-call detection
         m.conv3.weight.data.mul_(0.5)
         monkeypatch.setattr(M, "VERIFY_PACKED", True)
