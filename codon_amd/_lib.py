@@ -89,6 +89,7 @@ SIGNATURES = {
     "codon_ssim_l1_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P]),
     "codon_bicubic_upsample": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "codon_cac_apply_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _TP, _TP, _TP, _TP, _I, _P]),
+    "codon_ew_sum_mask": (C.c_int, [_I, _I, _I, _I, _TP, _I, _TP, _TP, _TP, _TP, _TP, _I, _P]),
     "codon_conv1x1_bwd_gated": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _TP, _P, _P, _S, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "codon_cac_bwd_reduce_acc": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _P, _P, _TP, _TP, _I, _I, _P]),
     "codon_weight_checksum_workspace_bytes": (_S, []),

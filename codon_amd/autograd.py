@@ -24,6 +24,9 @@ from .ops import Slice
 
 # 16-bit: dL/dw and dL/dx of the three 128 -> 64 1x1 convs in one pass each (codon_conv1x1_bwd); 0 = two kernels (A/B)
 FUSED_1X1_BWD = _os.environ.get("CODON_FUSED_1X1_BWD", "1") != "0"
+# dL/d(fuse) of the fusion trunk collected in one pass over the four dL/d(f_i) (ops.ew_sum_mask); 0 = a copy and three
+# read-modify-write passes (A/B)
+SUM_GFUSE = _os.environ.get("CODON_SUM_GFUSE", "1") != "0"
 # 16-bit: the CAC gate backward without its apply pass -- dL/d(pre) is formed in the staging of the 1x1 backward that
 # consumes it, dL/d(inputs) accumulates in the reduce pass (ops.cac_backward_fused); 0 = the four-kernel form (A/B)
 FUSED_CAC_BWD = _os.environ.get("CODON_FUSED_CAC_BWD", "1") != "0"
@@ -140,17 +143,12 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     del g_t
 
     # ---- fusion trunk, iterations 2..0                                                  :122-128
-    g_fuse = None                                   # running dL/dfuse (pre-mask)
+    g_fs = [g_f]                                    # dL/df_3, dL/df_2, ...: f_{i+1} = confuse_fuse(..) + fuse feeds each into dL/dfuse
     g_r2, g_stage = new(128), new(128)
     for i in (2, 1, 0):
         T = S[f"trunk{i}"]
         xin, r2 = T["x"], T["r2"]
         stage = restage(T["stage"], Slice(xin), ("conv8", 5), ("conv9", 3))
-        # f_{i+1} = confuse_fuse(r2) + fuse
-        if g_fuse is None:
-            g_fuse = g_f.clone()
-        else:
-            ops.ew_add_mask(Slice(g_fuse), Slice(g_f))
         bwd1x1("confuse_fuse", Slice(r2), Slice(g_f), Slice(g_r2))
         wgrad("conv10", Slice(stage), Slice(g_r2), 5)
         ops.conv2d(Slice(g_r2), Pd("conv10"), Slice(g_stage), 5, relu_mask=Slice(stage))
@@ -160,9 +158,17 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_prev), 5)
         ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_prev), 3, accumulate=True)
         g_f = g_prev
-    # f_0 is fuse itself; fuse = relu(conv7(oc4))                                         :119-120
-    ops.ew_add_mask(Slice(g_fuse), Slice(g_f), mask=Slice(S["fuse"]))
-    del g_f
+        g_fs.append(g_f)
+    # f_0 is fuse itself: dL/dfuse = (dL/df_3 + dL/df_2 + dL/df_1 + dL/df_0) * [fuse > 0]; fuse = relu(conv7(oc4))   :119-128
+    if SUM_GFUSE:
+        g_fuse = new(64)
+        ops.ew_sum_mask(Slice(g_fuse), [Slice(t) for t in g_fs], mask=Slice(S["fuse"]))
+    else:
+        g_fuse = g_fs[0].clone()
+        ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[1]))
+        ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[2]))
+        ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[3]), mask=Slice(S["fuse"]))
+    del g_f, g_fs
     wgrad("conv7", Slice(S["oc"]), Slice(g_fuse), 3)
     g_oc = new(128)                                 # dL/d[out | out_c] of block 4
     ops.conv2d(Slice(g_fuse), Pd("conv7"), Slice(g_oc), 3)

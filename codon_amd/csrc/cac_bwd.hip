@@ -380,6 +380,7 @@ int cac_bwd_apply_c8(int, int, int, const codon_tensor*, const codon_tensor*, co
                      const float*, const float*, const float*, const float*, const float*, const int*, const codon_tensor*,
                      const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int, hipStream_t);
 int ew_add_mask_c8(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int, hipStream_t);
+int ew_sum_mask_c8(int, int, int, int, const codon_tensor*, int, const codon_tensor* const*, const codon_tensor*, int, hipStream_t);
 static bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d)) % 16) == 0;
@@ -507,6 +508,19 @@ int ew_add_mask(int B, int H, int W, int C, const codon_tensor* dst, const codon
                        (const T*)s, s_img, (const T*)m, m_img, C, HW, accumulate);
   });
   return check_launch("ew_add_mask_kernel");
+}
+
+// dst = mask > 0 ? srcs[0] + ... + srcs[nsrc-1] : 0 (1 <= nsrc <= 4; dst aliases no source).  16-bit tensors: one pass, fp32
+// sum rounded once.  fp32 tensors: the same left-to-right sum as a copy and nsrc - 1 accumulating passes of ew_add_mask.
+int ew_sum_mask(int B, int H, int W, int C, const codon_tensor* dst, int nsrc, const codon_tensor* const* srcs,
+                const codon_tensor* mask, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32) return ew_sum_mask_c8(B, H, W, C, dst, nsrc, srcs, mask, dtype, stream);
+  CODON_REQUIRE(nsrc >= 1 && nsrc <= 4, CODON_ERR_UNSUPPORTED, "ew_sum_mask: %d sources (1..4)", nsrc);
+  for (int i = 0; i < nsrc; ++i) {
+    const int st = ew_add_mask(B, H, W, C, dst, srcs[i], i + 1 == nsrc ? mask : nullptr, i > 0 ? 1 : 0, dtype, stream);
+    if (st != CODON_OK) return st;
+  }
+  return CODON_OK;
 }
 
 }  // namespace codon

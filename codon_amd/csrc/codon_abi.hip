@@ -79,6 +79,7 @@ int cac_bwd_apply(int, int, int, const codon_tensor*, const codon_tensor*, const
                   hipStream_t);
 int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int,
                 hipStream_t);
+int ew_sum_mask(int, int, int, int, const codon_tensor*, int, const codon_tensor* const*, const codon_tensor*, int, hipStream_t);
 int head_fwd(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
 int cac_stats_tiles(int, int);
 int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t, const float*);
@@ -464,6 +465,20 @@ int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t chan
                 "ew_add_mask: null pointer or bad channel slice");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ew_add_mask: bad shape");
   return ew_add_mask(batch, height, width, channels, dst, src, mask, accumulate, dtype, (hipStream_t)stream);
+}
+
+int codon_ew_sum_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst, int32_t nsrc,
+                      const codon_tensor* src0, const codon_tensor* src1, const codon_tensor* src2, const codon_tensor* src3,
+                      const codon_tensor* mask, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "ew_sum_mask: dtype %d", dtype);
+  auto ok = [&](const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + channels <= t->ctotal; };
+  const codon_tensor* srcs[4] = {src0, src1, src2, src3};
+  CODON_REQUIRE(nsrc >= 1 && nsrc <= 4, CODON_ERR_BAD_ARG, "ew_sum_mask: %d sources (1..4)", nsrc);
+  for (int i = 0; i < nsrc; ++i)
+    CODON_REQUIRE(ok(srcs[i]) && srcs[i]->data != dst->data, CODON_ERR_BAD_ARG, "ew_sum_mask: source %d null, out of range or aliasing dst", i);
+  CODON_REQUIRE(channels > 0 && ok(dst) && (!mask || ok(mask)), CODON_ERR_BAD_ARG, "ew_sum_mask: null pointer or bad channel slice");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "ew_sum_mask: bad shape");
+  return ew_sum_mask(batch, height, width, channels, dst, nsrc, srcs, mask, dtype, (hipStream_t)stream);
 }
 
 int32_t codon_cac_bwd_tiles(int32_t height, int32_t width) {

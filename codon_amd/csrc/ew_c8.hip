@@ -576,6 +576,65 @@ int ew_add_mask_c8(int B, int H, int W, int C, const codon_tensor* dst, const co
   return check_launch("ew_add_mask_c8_kernel");
 }
 
+// dst = mask > 0 ? s0 + s1 [+ s2 [+ s3]] : 0, summed in fp32 in that order, rounded once (round 4: dL/d(fuse) of the
+// fusion trunk -- f_{i+1} = confuse_fuse(...) + fuse, CODON_x4.py:126-128 -- collected in ONE pass over the four dL/d(f_i)
+// instead of a copy and three read-modify-write passes); grid = (pixel blocks, planes, B)
+struct EwSum4 {
+  C8Slice s[4];
+};
+template <class E>
+__global__ __launch_bounds__(256) void ew_sum_mask_c8_kernel(C8Slice dst, EwSum4 src, int nsrc, C8Slice mask, int has_mask,
+                                                             int planes, long HW) {
+  const int b = blockIdx.z, pl = blockIdx.y;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned HW16 = 16u * (unsigned)HW;
+  const unsigned vo = q < HW ? 16u * (unsigned)q : C8_OOB;
+  const unsigned so = (unsigned)pl * HW16;
+  u32x4 raw[4], rm;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < nsrc) raw[i] = c8_ld(c8_rsrc(src.s[i], b, planes, HW16), vo, so);        // nsrc is launch-uniform
+  if (has_mask) rm = c8_ld(c8_rsrc(mask, b, planes, HW16), vo, so);
+  float v[8], t[8];
+  c8_unpack<E>(raw[0], v);
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < nsrc) {
+      c8_unpack<E>(raw[i], t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+  if (has_mask) {
+    c8_unpack<E>(rm, t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t[j] > 0.f ? v[j] : 0.f;
+  }
+  c8_st(c8_pack<E>(v), c8_rsrc(dst, b, planes, HW16), vo, so);
+}
+
+int ew_sum_mask_c8(int B, int H, int W, int C, const codon_tensor* dst, int nsrc, const codon_tensor* const* srcs,
+                   const codon_tensor* mask, int dtype, hipStream_t stream) {
+  const long HW = (long)H * W;
+  CODON_REQUIRE(B <= 65535 && C % 8 == 0 && nsrc >= 1 && nsrc <= 4, CODON_ERR_UNSUPPORTED,
+                "ew_sum_mask: batch %d / channels %d / %d sources (1..4)", B, C, nsrc);
+  CODON_REQUIRE(c8_slice_ok(dst->ctotal, dst->coff, C) && (!mask || c8_slice_ok(mask->ctotal, mask->coff, C)), CODON_ERR_BAD_ARG,
+                "ew_sum_mask: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
+  CODON_REQUIRE(HW * 2 * C < (long)C8_OOB, CODON_ERR_UNSUPPORTED, "ew_sum_mask: image too large for 32-bit buffer offsets");
+  const C8Slice d = c8_mk(dst, HW), m = mask ? c8_mk(mask, HW) : d;
+  EwSum4 s4;
+  for (int i = 0; i < 4; ++i) {
+    const codon_tensor* t = i < nsrc ? srcs[i] : srcs[0];
+    CODON_REQUIRE(t && t->data && c8_slice_ok(t->ctotal, t->coff, C), CODON_ERR_BAD_ARG, "ew_sum_mask: source %d", i);
+    s4.s[i] = c8_mk(t, HW);
+  }
+  const dim3 grid((unsigned)((HW + 255) / 256), C / 8, B);
+  if (dtype == CODON_F16)
+    hipLaunchKernelGGL(ew_sum_mask_c8_kernel<C8F16>, grid, dim3(256), 0, stream, d, s4, nsrc, m, mask ? 1 : 0, C / 8, HW);
+  else
+    hipLaunchKernelGGL(ew_sum_mask_c8_kernel<C8Bf16>, grid, dim3(256), 0, stream, d, s4, nsrc, m, mask ? 1 : 0, C / 8, HW);
+  return check_launch("ew_sum_mask_c8_kernel");
+}
+
 // ---- CAC backward, the two passes over the 64-channel tensors (math: cac_bwd.hip) --------------------------------------
 // A: per-(b,c) partial sums of dL/dch, dL/dz per pixel, first-arg-max pixel candidates of both global max-pools
 template <class E>

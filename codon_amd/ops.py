@@ -422,6 +422,22 @@ def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] =
                                       _dt(dst.buf), _stream(dev)), "ew_add_mask")
 
 
+def ew_sum_mask(dst: Slice, srcs, mask: Optional[Slice] = None):
+    """dst = mask > 0 ? sum(srcs) : 0 for 1..4 source slices (none aliasing dst); one pass for 16-bit tensors."""
+    lib = L.load()
+    srcs = list(srcs)
+    assert 1 <= len(srcs) <= 4
+    dev = _dev(dst.buf, *[s_.buf for s_ in srcs], mask.buf if mask else None)
+    B, H, W = _bhw(dst.buf)
+    assert all(s_.c == dst.c and _bhw(s_.buf) == (B, H, W) and s_.buf.dtype == dst.buf.dtype for s_ in srcs)
+    dt_, mt_ = dst.ct(), (mask.ct() if mask else None)
+    sts = [s_.ct() for s_ in srcs]
+    args = [C.byref(t) for t in sts] + [None] * (4 - len(sts))
+    with torch.cuda.device(dev):
+        L.check(lib.codon_ew_sum_mask(B, H, W, dst.c, C.byref(dt_), len(sts), *args,
+                                      C.byref(mt_) if mt_ is not None else None, _dt(dst.buf), _stream(dev)), "ew_sum_mask")
+
+
 def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
                  g_pre: Slice, g_pre_c: Slice, g_in: Slice, g_in_c: Slice, accumulate_in: bool):
     """Full backward of one CAC gate block.  Returns (dw1, db1, dw2, db2, dws) fp32 tensors."""

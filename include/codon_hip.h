@@ -263,6 +263,12 @@ int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codo
 int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels,
                       const codon_tensor* dst, const codon_tensor* src, const codon_tensor* mask,
                       int32_t accumulate, int32_t dtype, codon_stream_t stream);
+/* dst = mask > 0 ? src0 + ... + src{nsrc-1} : 0 (1 <= nsrc <= 4, summed left to right; dst aliases no source; mask may be
+ * null).  16-bit tensors: ONE pass, fp32 sum rounded once; fp32: the same result as a copy + nsrc-1 accumulating
+ * codon_ew_add_mask passes.  Collects dL/d(fuse) = sum of the trunk's dL/d(f_i) (autograd of CODON_x4.py:122-128). */
+int codon_ew_sum_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst,
+                      int32_t nsrc, const codon_tensor* src0, const codon_tensor* src1, const codon_tensor* src2,
+                      const codon_tensor* src3, const codon_tensor* mask, int32_t dtype, codon_stream_t stream);
 
 /* CAC gate backward, four launches (see codon_amd/csrc/cac_bwd.hip for the math):
  * reduce : g_z (B,1,H,W) = dL/d(spatial logits); part_gch (B,nt,64), part_arg (B,nt,128) int32,

@@ -152,6 +152,34 @@ def test_ew_add_mask(shape, dtype):
         assert torch.equal(ops.to_nchw(d1).float(), d0.to(dtype).float())
 
 
+@pytest.mark.parametrize("dtype", DT + [torch.float32])
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 33, 70)])
+def test_ew_sum_mask(shape, dtype):
+    """dst = mask > 0 ? s0 + s1 + s2 + s3 : 0 (round 4: dL/d(fuse) collected in one pass): fp32 sum in source order, rounded
+    once to the tensor's dtype; slices of wider buffers; 1..4 sources; with and without the mask."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    q = lambda seed: _rand((B, 128, H, W), seed).to(dtype).float().to(dev)
+    srcs_f = [q(11), q(12), q(13), q(14)]
+    mask_f = q(15)
+    conv = (lambda t: ops.from_nchw(t, dtype)) if dtype != torch.float32 else (lambda t: t.clone())
+    srcs, mask = [conv(t) for t in srcs_f], conv(mask_f)
+    for n in (1, 2, 3, 4):
+        for use_mask in (False, True):
+            dst = ops.new_act(B, 128, H, W, dtype, dev).fill_(float("nan"))
+            ops.ew_sum_mask(Slice(dst, 64, 64), [Slice(t, 0, 64) for t in srcs[:n]], mask=Slice(mask, 32, 64) if use_mask else None)
+            ref = srcs_f[0][:, :64].clone()
+            for t in srcs_f[1:n]:
+                ref = ref + t[:, :64]
+            if use_mask:
+                ref = torch.where(mask_f[:, 32:96] > 0, ref, torch.zeros_like(ref))
+            got = ops.to_nchw(dst).float()
+            assert torch.equal(got[:, 64:], ref.to(dtype).float()), (n, use_mask)
+            assert torch.isnan(got[:, :64]).all()
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 50, 70)])
 @pytest.mark.parametrize("accumulate_in", [False, True])
