@@ -18,7 +18,7 @@ LIB_NAME = "libcodon_hip.so"
 
 OK = 0
 F32, BF16, F16 = 0, 1, 2
-CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU, CONV_F16X3 = 1, 2, 4, 8, 16
+CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU, CONV_F16X3, CONV_MASK_SUM = 1, 2, 4, 8, 16, 32
 PACK_FWD, PACK_DGRAD, PACK_FWD_F16X3, PACK_CHAIN1X1, PACK_CHAIN1X1_F16X3 = 0, 1, 2, 3, 4
 CAC_FOLDS = 16   # CODON_CAC_FOLDS
 

@@ -27,6 +27,8 @@ FUSED_1X1_BWD = _os.environ.get("CODON_FUSED_1X1_BWD", "1") != "0"
 # dL/d(fuse) of the fusion trunk collected in one pass over the four dL/d(f_i) (ops.ew_sum_mask); 0 = a copy and three
 # read-modify-write passes (A/B)
 SUM_GFUSE = _os.environ.get("CODON_SUM_GFUSE", "1") != "0"
+# the ReLU mask of in2 applied by the last dgrad that accumulates into dL/d(in2) (CODON_CONV_MASK_SUM); 0 = a separate pass (A/B)
+MASK_IN_EPILOGUE = _os.environ.get("CODON_MASK_IN_EPILOGUE", "1") != "0"
 # 16-bit: the CAC gate backward without its apply pass -- dL/d(pre) is formed in the staging of the 1x1 backward that
 # consumes it, dL/d(inputs) accumulates in the reduce pass (ops.cac_backward_fused); 0 = the four-kernel form (A/B)
 FUSED_CAC_BWD = _os.environ.get("CODON_FUSED_CAC_BWD", "1") != "0"
@@ -217,8 +219,12 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_r2), Pd("conv3"), Slice(g_stage), 5, relu_mask=Slice(stage))
         wgrad("conv1", Slice(xin, 0, 64), Slice(g_stage, 0, 64), 3)
         wgrad("conv2", Slice(xin, 0, 64), Slice(g_stage, 64, 64), 5)
+        # block 0 writes into dL/d[inputs | inputs_c] itself, which is masked by in2 = relu(..) next: the LAST gradient that
+        # fans into each half applies that mask to the sum (CODON_CONV_MASK_SUM) -- no separate pass over the 128 channels
+        last0 = dict(relu_mask=Slice(in2, 0, 64), mask_sum=True) if (i == 0 and MASK_IN_EPILOGUE) else {}
+        last1 = dict(relu_mask=Slice(in2, 64, 64), mask_sum=True) if (i == 0 and MASK_IN_EPILOGUE) else {}
         ops.conv2d(Slice(g_stage, 0, 64), Pd("conv1"), Slice(g_x, 0, 64), 3, accumulate=acc0)
-        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True, **last0)
         # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
         stage_c = restage(Bk["stage_c"], Slice(xin, 64, 64), ("conv4", 5), ("conv5", 3))
         if gate is not None:
@@ -230,11 +236,12 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         wgrad("conv4", Slice(xin, 64, 64), Slice(g_stage, 0, 64), 5)
         wgrad("conv5", Slice(xin, 64, 64), Slice(g_stage, 64, 64), 3)
         ops.conv2d(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, accumulate=acc0)
-        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv5"), Slice(g_x, 64, 64), 3, accumulate=True)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv5"), Slice(g_x, 64, 64), 3, accumulate=True, **last1)
     del g_oc, g_pre2, g_r2, g_stage
 
     # ---- heads: in2 = [relu(conv_input(stem)) | relu(conv_input_c(stem_c))]            :68-72
-    ops.ew_add_mask(Slice(g_in2), None, mask=Slice(in2))
+    if not MASK_IN_EPILOGUE:
+        ops.ew_add_mask(Slice(g_in2), None, mask=Slice(in2))
     g_s = new(64)
     for nm_in, nm_ci, st, img, off in (("input", "conv_input", S["stem"], x, 0),
                                        ("input_c", "conv_input_c", S["stem_c"], y, 64)):

@@ -177,6 +177,9 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
     CODON_REQUIRE(d->r_coff >= 0 && d->r_coff + d->cout <= d->r_ctotal, CODON_ERR_BAD_ARG,
                   "conv2d_fwd: residual slice outside its buffer");
   }
+  CODON_REQUIRE(!(d->flags & CODON_CONV_MASK_SUM) ||
+                    ((d->flags & CODON_CONV_MASK_RELU) && (d->flags & CODON_CONV_ACCUM_OUT) && !(d->flags & (CODON_CONV_RELU | CODON_CONV_F16X3))),
+                CODON_ERR_BAD_ARG, "conv2d_fwd: MASK_SUM needs MASK_RELU | ACCUM_OUT (and neither RELU nor F16X3)");
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_fwd: packed weights not 16-byte aligned");
   if (d->dtype == CODON_BF16 || d->dtype == CODON_F16)
     return conv2d_fwd_bf16(d, x, w_packed, y, residual, (hipStream_t)stream);

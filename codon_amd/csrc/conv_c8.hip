@@ -498,10 +498,11 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   // ReLU / residual / mask / accumulate as compile-time variants selected by wave-uniform branches
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
-  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c, auto ms_c) {
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int RES = decltype(res_c)::value;
     constexpr bool ACC = decltype(acc_c)::value;
+    constexpr bool MS = decltype(ms_c)::value;      // MASK_SUM: the mask applies to conv + previous value
 #pragma unroll
     for (int i = 0; i < PSEG; ++i) {
 #pragma unroll
@@ -525,8 +526,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
             float v = acc[i][t][8 * g + j];
             if constexpr (RELU) v = relu1_c8(v);
             if constexpr (RES == RESC8_ADD) v += r8[j];
-            if constexpr (RES == RESC8_MASK) v = r8[j] > 0.f ? v : 0.f;
+            if constexpr (RES == RESC8_MASK && !MS) v = r8[j] > 0.f ? v : 0.f;
             if constexpr (ACC) v += a8[j];
+            if constexpr (RES == RESC8_MASK && MS) v = r8[j] > 0.f ? v : 0.f;
             v8[j] = v;
           }
           c8_st(c8_pack<E>(v8), yrsrc, vo[i], cplane(t, g));
@@ -542,9 +544,13 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   const int res_mode = !p.res ? RESC8_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RESC8_MASK
                                            : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RESC8_ADD : RESC8_NONE;
   const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  const bool msum = p.flags & CODON_CONV_MASK_SUM;
   auto by_acc = [&](auto relu_c, auto res_c) {
-    if (accum) epi(relu_c, res_c, T{});
-    else epi(relu_c, res_c, F{});
+    if constexpr (!decltype(relu_c)::value && decltype(res_c)::value == RESC8_MASK) {
+      if (accum && msum) { epi(relu_c, res_c, T{}, T{}); return; }
+    }
+    if (accum) epi(relu_c, res_c, T{}, F{});
+    else epi(relu_c, res_c, F{}, F{});
   };
   auto by_res = [&](auto relu_c) {
     if (res_mode == RESC8_NONE) by_acc(relu_c, R0{});
@@ -586,6 +592,7 @@ __global__ __launch_bounds__(256) void conv1x1_c8_kernel(const ConvC8Params p) {
   const bool addr = (p.flags & CODON_CONV_ADD_RESIDUAL) && rg;
   const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
   const bool mask = (p.flags & CODON_CONV_MASK_RELU) && rg;
+  const bool msum = (p.flags & CODON_CONV_MASK_SUM) != 0;
 
   unsigned vo[2];                                            // tile i: pixel pix0 + 32 i + l31, plane `half`
 #pragma unroll
@@ -658,9 +665,12 @@ __global__ __launch_bounds__(256) void conv1x1_c8_kernel(const ConvC8Params p) {
             if (relu) v = fmaxf(v, 0.f);
             if constexpr (HR) {
               if (addr) v += r8[j];
-              if (mask) v = r8[j] > 0.f ? v : 0.f;
+              if (mask && !msum) v = r8[j] > 0.f ? v : 0.f;
             }
             if constexpr (HA) v += a8[j];
+            if constexpr (HR) {
+              if (mask && msum) v = r8[j] > 0.f ? v : 0.f;
+            }
             v8[j] = v;
           }
           c8_st(c8_pack<E>(v8), yrsrc, vo[i], cplane(t0 + t, g));

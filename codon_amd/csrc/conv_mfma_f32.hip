@@ -415,10 +415,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   // ReLU / residual / accumulate as compile-time variants selected by wave-uniform branches: inside a variant every
   // element costs its store plus at most two VALU ops, and the 16 loads of a tile are issued back to back.
   const float* const ybase = p.y + (long)b * p.y_img + p.y_base;
-  auto epi = [&](auto relu_c, auto res_c, auto acc_c) {
+  auto epi = [&](auto relu_c, auto res_c, auto acc_c, auto ms_c) {
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int RES = decltype(res_c)::value;
     constexpr bool ACC = decltype(acc_c)::value;
+    constexpr bool MS = decltype(ms_c)::value;      // MASK_SUM: the mask applies to conv + previous value
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const __amdgpu_buffer_rsrc_t yrsrc = planes(ybase, t * 32, 32), rrsrc = planes(rbase, t * 32, 32);
@@ -438,8 +439,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
           float v = acc[i][t][r];
           if constexpr (RELU) v = relu1(v);
           if constexpr (RES == RES_ADD) v += rv[r];
-          if constexpr (RES == RES_MASK) v = rv[r] > 0.f ? v : 0.f;
+          if constexpr (RES == RES_MASK && !MS) v = rv[r] > 0.f ? v : 0.f;
           if constexpr (ACC) v += av[r];
+          if constexpr (RES == RES_MASK && MS) v = rv[r] > 0.f ? v : 0.f;
           buf_st(v, yrsrc, vo[i], inplane(r));
         }
       }
@@ -453,9 +455,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   const int res_mode = !p.res ? RES_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RES_MASK
                                          : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RES_ADD : RES_NONE;
   const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
+  const bool msum = p.flags & CODON_CONV_MASK_SUM;
   auto by_acc = [&](auto relu_c, auto res_c) {
-    if (accum) epi(relu_c, res_c, T{});
-    else epi(relu_c, res_c, F{});
+    if constexpr (!decltype(relu_c)::value && decltype(res_c)::value == RES_MASK) {
+      if (accum && msum) { epi(relu_c, res_c, T{}, T{}); return; }
+    }
+    if (accum) epi(relu_c, res_c, T{}, F{});
+    else epi(relu_c, res_c, F{}, F{});
   };
   auto by_res = [&](auto relu_c) {
     if (res_mode == RES_NONE) by_acc(relu_c, R0{});

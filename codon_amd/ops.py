@@ -134,9 +134,10 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
 
 def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = False,
            residual: Optional[Slice] = None, accumulate: bool = False, relu_mask: Optional[Slice] = None,
-           f16x3: bool = False):
+           f16x3: bool = False, mask_sum: bool = False):
     """y = conv(x) [relu] [+ residual] ; relu_mask: y = (relu_mask > 0) ? conv(x) : 0 (backward through a
-    ReLU given its output); accumulate: y += result."""
+    ReLU given its output); accumulate: y += result; mask_sum (with relu_mask and accumulate): the mask applies to the
+    sum, y = (relu_mask > 0) ? conv(x) + y : 0."""
     if relu_mask is not None:
         assert residual is None
         residual = relu_mask
@@ -145,6 +146,9 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
     B, H, W = _bhw(x.buf)
     assert _bhw(y.buf) == (B, H, W)
     flags = (L.CONV_RELU if relu else 0) | (L.CONV_ACCUM_OUT if accumulate else 0) | (L.CONV_F16X3 if f16x3 else 0)
+    if mask_sum:
+        assert relu_mask is not None and accumulate and not relu
+        flags |= L.CONV_MASK_SUM
     if relu_mask is not None:
         flags |= L.CONV_MASK_RELU
     elif residual is not None:

@@ -49,9 +49,11 @@ enum {
   CODON_CONV_ACCUM_OUT = 4,    /* y += conv                 (backward: grads that fan in)    */
   CODON_CONV_MASK_RELU = 8,    /* y = residual > 0 ? conv : 0   (backward through a ReLU whose OUTPUT is
                                   passed in the residual slot; applied before ACCUM_OUT's add)      */
-  CODON_CONV_F16X3 = 16        /* OPT-IN, fp32 tensors, k in {3,5}: split-precision evaluation -- operands split
+  CODON_CONV_F16X3 = 16,       /* OPT-IN, fp32 tensors, k in {3,5}: split-precision evaluation -- operands split
                                   into fp16 hi+lo, three f16 MFMAs per product, fp32 accumulate (~2^-22 per
                                   product; |activations| < 65504).  w_packed must come from CODON_PACK_FWD_F16X3. */
+  CODON_CONV_MASK_SUM = 32     /* with MASK_RELU | ACCUM_OUT: the mask applies to the SUM, y = residual > 0 ? conv + y : 0
+                                  (the last gradient that fans into a ReLU output: no separate mask pass)          */
 };
 
 enum { CODON_PACK_FWD = 0, CODON_PACK_DGRAD = 1, CODON_PACK_FWD_F16X3 = 2, CODON_PACK_CHAIN1X1 = 3,

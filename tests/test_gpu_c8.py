@@ -153,6 +153,29 @@ def test_ew_add_mask(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT + [torch.float32])
+@pytest.mark.parametrize("k", [3, 5])
+def test_conv_mask_sum_equals_accumulate_then_mask(k, dtype):
+    """CODON_CONV_MASK_SUM (round 4): y = mask > 0 ? conv + y : 0 in the epilogue of the LAST gradient that fans into a
+    ReLU output == the accumulating conv followed by a mask pass (codon_ew_add_mask), bit for bit."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 2, 21, 37
+    conv = (lambda t: ops.from_nchw(t, dtype)) if dtype != torch.float32 else (lambda t: t.clone())
+    q = lambda c, seed: _rand((B, c, H, W), seed).to(dtype).float().to(dev)
+    w = _rand((64, 64, k, k), 2, scale=(2.0 / (k * k * 64)) ** 0.5).to(dev)
+    wp = ops.packed_weight(w, L.PACK_DGRAD, dtype)
+    gy, prev, act = conv(q(64, 3)), q(128, 5), conv(q(128, 4))
+    y0, y1 = conv(prev), conv(prev)
+    ops.conv2d(Slice(gy), wp, Slice(y0, 64, 64), k, accumulate=True)
+    ops.ew_add_mask(Slice(y0, 64, 64), None, mask=Slice(act, 0, 64))
+    ops.conv2d(Slice(gy), wp, Slice(y1, 64, 64), k, accumulate=True, relu_mask=Slice(act, 0, 64), mask_sum=True)
+    assert torch.equal(y1, y0)
+    frac = float((ops.to_nchw(y1)[:, 64:] == 0).float().mean())
+    assert 0.3 < frac < 0.7                                           # the mask did something
+
+
+@pytest.mark.parametrize("dtype", DT + [torch.float32])
 @pytest.mark.parametrize("shape", [(2, 19, 45), (1, 1, 1), (1, 33, 70)])
 def test_ew_sum_mask(shape, dtype):
     """dst = mask > 0 ? s0 + s1 + s2 + s3 : 0 (round 4: dL/d(fuse) collected in one pass): fp32 sum in source order, rounded
@@ -405,6 +428,18 @@ def test_training_schedules_agree_bit_for_bit():
         A.FUSED_CAC_BWD = oldc
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], g3[n]), n
+    # ... and the ReLU mask of in2 applied in the last dgrad's epilogue or as a pass
+    oldm = A.MASK_IN_EPILOGUE
+    try:
+        A.MASK_IN_EPILOGUE = not oldm
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g4 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.MASK_IN_EPILOGUE = oldm
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], g4[n]), n
 
 
 @pytest.mark.parametrize("dtype", DT)
