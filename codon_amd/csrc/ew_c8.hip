@@ -726,7 +726,10 @@ __global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
     C8Slice g_out, C8Slice g_outc, C8Slice pre, C8Slice pre_c, C8Slice g_in, C8Slice g_in_c, const float* __restrict__ ch,
     const float* __restrict__ sp, const float* __restrict__ pools, const float* __restrict__ pooled, float* __restrict__ g_z,
     float* __restrict__ part_gch, int* __restrict__ part_arg, int* __restrict__ argch, long HW, int ntiles, int accumulate_in) {
-  constexpr int KH = 4;                               // pixels in flight per thread
+#ifndef CODON_CAC_ACC_KH
+#define CODON_CAC_ACC_KH 4
+#endif
+  constexpr int KH = CODON_CAC_ACC_KH;                // pixels in flight per thread
   __shared__ float red_s[64][4];
   __shared__ int red_a[128][4];
   __shared__ float st_sp[EW_NP][256], st_gsp[EW_NP][256], st_pmx[EW_NP][256];
