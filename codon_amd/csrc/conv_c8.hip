@@ -93,8 +93,19 @@ template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (CO
 // waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
 template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : (KS == 3 && COUT == 64) ? CODON_C8_NW364 : 4; };
 
-template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
-__global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
+// PERSIST (round 4): a workgroup walks a contiguous RANGE of tiles instead of one.  The stage pipeline simply continues
+// across the tile edge: the last stage of tile t requests stage 0 of tile t+1 (its first halo chunk through tile t+1's
+// gather plan, the first weight row), the epilogue of tile t runs while those pieces are in flight -- the per-tile
+// prologue (plan + a full memory round trip with nothing to overlap it inside the workgroup) is paid once per range.
+// Same MFMAs on the same operands in the same order per tile: results are bit-identical to the one-tile-per-workgroup form.
+// RESW (with PERSIST): the WHOLE packed filter stays resident in LDS for the workgroup's lifetime -- loaded once, never
+// re-staged (a one-tile conv3x3 64->64 workgroup stages 72 KB of weights for 43 KB of input and 32 KB of output); the only
+// per-chunk traffic left is the halo tile, and the only barrier the one that publishes it (per chunk, not per stage).
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
+          bool RESW = false>
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
+  static_assert(!PERSIST || (!FUSE && !GATE && CODON_C8_DMA != 0), "the tile loop exists for the plain LDS-DMA convs");
+  static_assert(!RESW || PERSIST, "a resident filter pays only over many tiles");
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
   typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
@@ -110,11 +121,14 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   constexpr int CT = COUT / 32;
   constexpr int NST = NCHUNK * KS;
   constexpr int XE = (XS + NT - 1) / NT, WE = (WS + NT - 1) / NT;
-  constexpr int XSP = XE * NT, WSP = WE * NT;     // padded to whole staging rounds (no store predicates)
+  // padded to whole staging rounds (no store predicates); RESW: to whole waves (a wave past the tile issues nothing)
+  constexpr int XSP = RESW ? ((XS + 63) / 64) * 64 : XE * NT, WSP = WE * NT;
+  constexpr int WTOT = RESW ? NST * WS : 2 * WSP;  // weight region: the whole filter, or two stage buffers
   static_assert(NCHUNK % 2 == 0, "the stage loop is unrolled over chunk pairs");
-  static_assert(2 * XSP * 16 < 65536 && 2 * WSP * 16 < 65536, "LDS immediates are 16 bits per region");
+  static_assert((XSP + (KS + PSEG) * XQ) * 16 < 65536 && 2 * WSP * 16 < 65536 && (!RESW || 2 * KS * WS * 16 < 65536),
+                "LDS immediates are 16 bits per region");
 
-  __shared__ uint4 lds[2 * XSP + 2 * WSP];
+  __shared__ uint4 lds[2 * XSP + WTOT];
   uint4* const xs0 = lds;
   uint4* const ws0 = lds + 2 * XSP;
 
@@ -122,16 +136,32 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
 
-  unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
-  const int tx = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty = bid % p.tiles_y;
-  const int b = bid / p.tiles_y;
-  const int tx0 = tx * TW, ty0 = ty * TH;
+  // this workgroup's tiles: one (the XCD-remapped block index), or -- PERSIST -- every gridDim.x-th tile from there: at any
+  // moment the resident workgroups work on ~gridDim.x CONSECUTIVE tiles, as a one-tile-per-workgroup launch does, so
+  // neighbouring tiles still meet in an XCD's L2 (a contiguous range per workgroup was measured first: 0.96 vs 0.82 ms,
+  // every halo re-read came from HBM)
+  int t_cur, t_step;
+  if constexpr (PERSIST) {
+    t_cur = (int)xcd_remap(blockIdx.x, gridDim.x);
+    t_step = (int)gridDim.x;
+  } else {
+    t_cur = (int)xcd_remap(blockIdx.x, (unsigned)p.nblk);
+    t_step = p.nblk;
+  }
+  int tx, ty, b;
+  auto decode = [&](int tile, int& tx_, int& ty_, int& b_) {
+    unsigned bid = (unsigned)tile;
+    tx_ = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    ty_ = bid % p.tiles_y;
+    b_ = bid / p.tiles_y;
+  };
+  decode(t_cur, tx, ty, b);
+  int tx0 = tx * TW, ty0 = ty * TH;
   const int H = p.H, W = p.W;
   const unsigned HW16 = 16u * (unsigned)H * (unsigned)W;   // bytes per 8-channel plane
 
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.x + (long)b * p.x_img + p.x_base), 0, (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(NST * WS * 16), C8_RSRC_FLAGS);
@@ -142,6 +172,18 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   int xcb[GATE ? XE : 1];        // GATE: plane (0 / 1) of the element inside its chunk, and its pixel's spatial gate
   float xsp[GATE ? XE : 1];
   unsigned xown = 0;             // GATE: bit k = element k is one of the tile's OWN pixels (not halo), inside the image
+  // PERSIST: the gather plan of another tile, straight into xoff[] (element e = tid + NT k -> (cb, r, q) by constant divisions)
+  auto plan_for = [&](int ty0_, int tx0_) {
+#pragma unroll
+    for (int k = 0; k < (PERSIST ? XE : 0); ++k) {
+      const int e_ = tid + k * NT;
+      const int cb_ = e_ / (XR * XQ), rem_ = e_ - cb_ * (XR * XQ);
+      const int r_ = rem_ / XQ, q_ = rem_ - r_ * XQ;
+      const int gy = ty0_ + r_ - PAD, gx = tx0_ + q_ - PAD;
+      const bool ok = cb_ < NCB && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xoff[k] = ok ? (unsigned)cb_ * HW16 + 16u * (unsigned)(gy * W + gx) : C8_OOB;
+    }
+  };
   {
     constexpr int DQ = NT % XQ, DR = (NT / XQ) % XR, DC = (NT / XQ) / XR;
     int cb = tid / (XR * XQ);
@@ -188,22 +230,23 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   u32x4 xg[GATE ? XEH : 1];
   u32x4 wr[DMA ? 1 : WE];
 
-#define LOAD_X(chunk_, buf_, k0_, k1_)                                                  \
+#define LOAD_XP(rs_, off_, chunk_, buf_, k0_, k1_)                                      \
   {                                                                                     \
     const unsigned so_ = (unsigned)(chunk_) * (unsigned)NCB * HW16;                     \
     _Pragma("unroll") for (int k = (k0_); k < (k1_); ++k) {                             \
       if constexpr (DMA) {                                                              \
-        const unsigned vo_ = xoff[k];   /* passed as xoff[k] the host pass drops the kernel's stub (hipcc 7.2) */ \
+        const unsigned vo_ = off_[k];   /* passed as off_[k] the host pass drops the kernel's stub (hipcc 7.2) */ \
         /* a wave whose 64 slots all lie past the tile (last round) issues nothing: the slots are never read */ \
         if (XS % NT == 0 || k < XE - 1 || k * NT + wave_u * 64 < XS)                    \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(lds + (buf_) * XSP + k * NT + wave_u * 64), 16, \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void*)(lds + (buf_) * XSP + k * NT + wave_u * 64), 16, \
                                                    vo_, so_, 0, 0);                     \
       } else {                                                                          \
-        xv[k - (k0_)] = c8_ld(xrsrc, xoff[k], so_);                                     \
-        if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, xoff[k], so_);                 \
+        xv[k - (k0_)] = c8_ld(rs_, off_[k], so_);                                       \
+        if constexpr (GATE) xg[k - (k0_)] = c8_ld(grsrc, off_[k], so_);                 \
       }                                                                                 \
     }                                                                                   \
   }
+#define LOAD_X(chunk_, buf_, k0_, k1_) LOAD_XP(xrsrc, xoff, chunk_, buf_, k0_, k1_)
   // GATE: the staged vector is pre * (ch * sp) + inputs, formed in fp32 and rounded once -- the arithmetic of
   // cac_apply_c8_kernel followed by a plain load, bit for bit (out-of-image elements: 0 * g + 0 = 0)
 #define STORE_X(chunk_, buf_, k0_, k1_)   /* buf_ compile time: immediate offsets */    \
@@ -226,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
     }                                                                                   \
   }
 #define LOAD_W(stage_, buf_)                                                            \
-  {                                                                                     \
+  if constexpr (!RESW) {                                                                \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
       if constexpr (DMA) {                                                              \
@@ -244,12 +287,6 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   }
 
   f32x16 acc[PSEG][CT];
-#pragma unroll
-  for (int i = 0; i < PSEG; ++i)
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
   if constexpr (GATE) __syncthreads();        // chs
   if constexpr (XE1 > 0) {
@@ -258,15 +295,41 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   }
   LOAD_X(0, 0, XE1, XE);
   LOAD_W(0, 0);
+  if constexpr (RESW) {                              // the whole filter, once: NST * WS vectors in rounds of NT
+    constexpr int WALL = NST * WS, WR = (WALL + NT - 1) / NT;
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const unsigned wo_ = (WALL % NT == 0 || k < WR - 1 || tid + k * NT < WALL) ? wvo : C8_OOB;
+      if (WALL % NT == 0 || k < WR - 1 || k * NT + wave_u * 64 < WALL)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + k * NT + wave_u * 64), 16, wo_,
+                                                 (unsigned)k * (unsigned)(NT * 16), 0, 0);
+    }
+  }
   STORE_X(0, 0, XE1, XE);
   STORE_W(0);
   if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this wave's pieces have landed
   __syncthreads();
 
+  static_assert(!PERSIST || (NST % 2 == 0), "the tile loop re-enters with stage parity 0");
+#pragma unroll 1
+  for (;;) {       // tiles of this workgroup (one trip unless PERSIST)
+  const bool next_tile = PERSIST && (t_cur + t_step < p.nblk);       // wave-uniform
+  // the CURRENT tile's coordinates for the epilogue (tx, ty, b, tx0, ty0 move on to the next tile inside the last chunk)
+  const int tx_e = tx, ty_e = ty, b_e = b, tx0_e = tx0, ty0_e = ty0;
+  (void)tx_e; (void)ty_e;
+#pragma unroll
+  for (int i = 0; i < PSEG; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
   // stage (chunk, dy): weights of filter row dy for 16 channels in ws[(chunk*KS + dy) & 1], the chunk's halo tile in
   // xs[chunk & 1].  Unrolled over (chunk parity, dy): KS odd, so the stage parity is (par + dy) & 1.
 #pragma unroll 1
   for (int c2 = 0; c2 < NCHUNK; c2 += 2) {
+    const lds_rd wrd_c2 = wrd + (RESW ? c2 * KS * WS : 0);       // resident filter: this chunk pair's rows
+    (void)wrd_c2;
     static_for_c8<2 * KS>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int par = u / KS, dy = u % KS;                    // chunk parity, filter row
@@ -275,12 +338,31 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       const int s = chunk * KS + dy;
       constexpr bool tail = (par == 1 && dy == KS - 1);           // last stage of the pair
       const bool has_next = !tail || (c2 + 2 < NCHUNK);
+      // PERSIST: behind the last chunk comes chunk 0 / stage 0 of the NEXT tile (buffer parities continue: NST is even).
+      // The last chunk's halo tile was requested during the chunk before it, so from its first stage on xoff[] / xrsrc
+      // are free to become the next tile's plan: no second set of plan registers is ever live.
+      const bool wrap = PERSIST && par == 1 && (c2 + 2 >= NCHUNK) && next_tile;   // wave-uniform
+      if constexpr (PERSIST && par == 1 && dy == 0) {
+        if (wrap) {
+          decode(t_cur + t_step, tx, ty, b);
+          tx0 = tx * TW; ty0 = ty * TH;
+          plan_for(ty0, tx0);
+          xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long)b * p.x_img + p.x_base), 0,
+                                                    (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
+        }
+      }
       if (has_next) {
         LOAD_W(s + 1, sbuf ^ 1);
         if constexpr (dy == KS - 1) LOAD_X(chunk + 1, par ^ 1, XE1, XE);
+      } else if constexpr (PERSIST && tail) {
+        if (wrap) {
+          LOAD_W(0, sbuf ^ 1);
+          LOAD_X(0, par ^ 1, XE1, XE);
+        }
       }
       if constexpr (XE1 > 0 && dy == KS - 2) {
-        if (!(par == 1 && c2 + 2 >= NCHUNK)) LOAD_X(chunk + 1, par ^ 1, 0, XE1);
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) { LOAD_X(chunk + 1, par ^ 1, 0, XE1); }
+        else if constexpr (PERSIST) { if (wrap) LOAD_X(0, par ^ 1, 0, XE1); }
       }
 
       // operand fetch one filter tap ahead of its MFMAs, in two register sets.  PIN: sched_barrier holds that order
@@ -289,7 +371,8 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       vec8 a[2][CT], bv[2][PSEG];
 #define FETCH_A(q_, t_)                                                                                   \
   {                                                                                                       \
-    const u32x4 v_ = wrd[sbuf * WSP + (q_) * NCB * COUT + (t_) * 32];                                     \
+    const u32x4 v_ = RESW ? wrd_c2[(par * KS + dy) * WS + (q_) * NCB * COUT + (t_) * 32]                  \
+                          : wrd[sbuf * WSP + (q_) * NCB * COUT + (t_) * 32];                              \
     a[(q_) & 1][t_] = *reinterpret_cast<const vec8*>(&v_);                                                \
   }
 #define FETCH_B(q_)                                                                                       \
@@ -324,27 +407,31 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
         STORE_W(sbuf ^ 1);
         if constexpr (dy == KS - 1) STORE_X(chunk + 1, par ^ 1, XE1, XE);
       }
-      if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier: DMA pieces of the next stage are in LDS
-      __syncthreads();
+      // RESW: nothing changes hands inside a chunk -- one barrier per chunk, the one that publishes the next halo tile
+      if constexpr (!RESW || dy == KS - 1) {
+        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier: DMA pieces of the next stage are in LDS
+        __syncthreads();
+      }
     });
   }
 #undef LOAD_X
+#undef LOAD_XP
 #undef STORE_X
 #undef LOAD_W
 #undef STORE_W
 
   // epilogue.  Lane term of every output address: this lane's pixel in plane `half`; the plane pair (t, g) is wave
   // uniform and goes into the scalar offset.  Off-image pixels are out of range.
-  const int gx = tx0 + l31;
+  const int gx = tx0_e + l31;
   unsigned vo[PSEG];
 #pragma unroll
   for (int i = 0; i < PSEG; ++i) {
-    const int gy = ty0 + wave * PSEG + i;
+    const int gy = ty0_e + wave * PSEG + i;
     vo[i] = (gx < W && gy < H) ? (unsigned)half * HW16 + 16u * (unsigned)(gy * W + gx) : C8_OOB;
   }
   const bool relu = p.flags & CODON_CONV_RELU;
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res ? p.res + (long)b * p.r_img + p.r_base : p.x), 0, (int)((unsigned)((FUSE ? 64 : COUT) / 8) * HW16),
+      (void*)(p.res ? p.res + (long)b_e * p.r_img + p.r_base : p.x), 0, (int)((unsigned)((FUSE ? 64 : COUT) / 8) * HW16),
       C8_RSRC_FLAGS);
   auto cplane = [&](int t, int g) { return (unsigned)(t * 4 + 2 * g) * HW16; };
 
@@ -367,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
         }
     if (p.y) {
       const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+          (void*)(p.y + (long)b_e * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
 #pragma unroll
       for (int i = 0; i < PSEG; ++i)
 #pragma unroll
@@ -377,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
     }
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 2, C8_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.y2 + (long)b * p.y2_img + p.y2_base), 0, (int)(8u * HW16), C8_RSRC_FLAGS);
+        (void*)(p.y2 + (long)b_e * p.y2_img + p.y2_base), 0, (int)(8u * HW16), C8_RSRC_FLAGS);
     const unsigned w2vo = (unsigned)lane * 16u;
     f32x16 d[2][PSEG];
 #pragma unroll
@@ -446,9 +533,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
       for (int i = 0; i < PSEG; ++i) {
         const float m2 = fmaxf(pmx[i], __shfl_xor(pmx[i], 32, 64)), s2 = psm[i] + __shfl_xor(psm[i], 32, 64);
         if (half == 0 && valid[i]) {
-          const long q = (long)(ty0 + wave * PSEG + i) * W + gx;
-          p.st_pool[(long)b * 2 * HWl + q] = m2;
-          p.st_pool[(long)b * 2 * HWl + HWl + q] = s2;
+          const long q = (long)(ty0_e + wave * PSEG + i) * W + gx;
+          p.st_pool[(long)b_e * 2 * HWl + q] = m2;
+          p.st_pool[(long)b_e * 2 * HWl + HWl + q] = s2;
         }
       }
       // per channel: transpose through LDS (free after the last stage's barrier): lane L writes its 32 values as a
@@ -486,9 +573,9 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
           m = fmaxf(m, red[(NW + w) * 64 + lane]);
         }
         const int ch = (l31 >> 4) * 32 + ((l31 >> 3) & 1) * 16 + 8 * half + (l31 & 7);   // value index -> channel (swap23 layout)
-        const long tile = (long)ty * p.tiles_x + tx;
+        const long tile = (long)ty_e * p.tiles_x + tx_e;
         float2* out = reinterpret_cast<float2*>(p.st_part) +
-                      (((long)b * p.tiles_x * p.tiles_y + tile) * 128 + p.st_choff + ch);
+                      (((long)b_e * p.tiles_x * p.tiles_y + tile) * 128 + p.st_choff + ch);
         *out = make_float2(s, m);
       }
     }
@@ -497,7 +584,7 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
 
   // ReLU / residual / mask / accumulate as compile-time variants selected by wave-uniform branches
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.y + (long)b * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
+      (void*)(p.y + (long)b_e * p.y_img + p.y_base), 0, (int)((unsigned)(COUT / 8) * HW16), C8_RSRC_FLAGS);
   auto epi = [&](auto relu_c, auto res_c, auto acc_c, auto ms_c) {
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int RES = decltype(res_c)::value;
@@ -559,6 +646,14 @@ __global__ __launch_bounds__(64 * NW, ((KS == 3 && COUT == 64) ? CODON_C8_OCC3 :
   };
   if (relu) by_res(T{});
   else by_res(F{});
+
+  if constexpr (!PERSIST) {
+    break;
+  } else {
+    if (!next_tile) break;
+    t_cur += t_step;       // its plan, descriptor and coordinates were installed in the last chunk; stage 0 is in LDS
+  }
+  }   // tiles
 }
 
 // ---- 1x1 convolution (stand-alone confuse* and their dgrad): HBM-bound ---------------------------------------------
@@ -777,6 +872,46 @@ static int launch_conv1x1_c8(const codon_conv_desc* d, const void* x, const void
   return check_launch("conv1x1_c8_kernel");
 }
 
+// Workgroups of `kernel` that are resident on the whole chip at once (CUs x occupancy), per device; 0 if unknown.
+template <class K>
+static int c8_resident_blocks(K kernel, int threads) {
+  constexpr int MAXDEV = 64;
+  static int cached[MAXDEV];
+  static bool init = [] { for (int i = 0; i < MAXDEV; ++i) cached[i] = -1; return true; }();
+  (void)init;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { (void)hipGetLastError(); return 0; }
+  int v = __atomic_load_n(&cached[dev], __ATOMIC_ACQUIRE);
+  if (v < 0) {
+    int ncu = 0, occ = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kernel, threads, 0) != hipSuccess)
+      ncu = occ = 0;
+    (void)hipGetLastError();
+    v = ncu * occ;
+    __atomic_store_n(&cached[dev], v, __ATOMIC_RELEASE);
+  }
+  return v;
+}
+
+// PERSIST launches: one resident generation of workgroups, each walking >= C8_PERSIST_MIN_TILES tiles; smaller problems
+// keep one tile per workgroup (nothing to amortise, and the small-grid latency path wants many short workgroups)
+#ifndef CODON_C8_PERSIST3
+#define CODON_C8_PERSIST3 0        // plain conv3x3 64->64 through the tile loop with STAGED weights (measured: no gain)
+#endif
+#ifndef CODON_C8_PERSIST5
+#define CODON_C8_PERSIST5 0        // plain conv5x5 64->64 likewise
+#endif
+constexpr int C8_PERSIST_MIN_TILES = 4;
+#ifndef CODON_C8_RESIDENT3
+#define CODON_C8_RESIDENT3 1       // plain conv3x3 64->64 with the whole filter resident in LDS (0: the staged kernel, A/B)
+#endif
+constexpr int C8_RESIDENT_MIN_TILES = 8;
+template <int KS, int CIN, int COUT, bool FUSE, bool GATE> struct ConvC8Persist {
+  static constexpr bool value = !FUSE && !GATE && CODON_C8_DMA != 0 && CIN == 64 && COUT == 64 &&
+                                ((KS == 3 && CODON_C8_PERSIST3 != 0) || (KS == 5 && CODON_C8_PERSIST5 != 0));
+};
+
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
@@ -786,6 +921,30 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
+  if constexpr (KS == 3 && CIN == 64 && COUT == 64 && !FUSE && !GATE && CODON_C8_DMA != 0 && CODON_C8_RESIDENT3 != 0) {
+    // resident-filter persistent form: 16 waves, 32 x 32 tiles, one workgroup per CU
+    constexpr int NWR = 16, THR = NWR * ConvC8Pseg<KS, COUT>::value;
+    constexpr bool RW = true;
+    const int res = c8_resident_blocks(conv_c8_kernel<E, KS, CIN, COUT, FUSE, NWR, GATE, true, RW>, 64 * NWR);
+    const int tyr = (d->height + THR - 1) / THR;
+    const long nblkr = (long)p.tiles_x * tyr * d->batch;
+    if (res > 0 && nblkr >= (long)res * C8_RESIDENT_MIN_TILES) {
+      ConvC8Params pr = p;
+      pr.tiles_y = tyr;
+      pr.nblk = (int)nblkr;
+      hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NWR, GATE, true, RW>), dim3((unsigned)res), dim3(64 * NWR), 0,
+                         stream, pr);
+      return check_launch("conv_c8_kernel<resident>");
+    }
+  }
+  if constexpr (ConvC8Persist<KS, CIN, COUT, FUSE, GATE>::value) {
+    const int res = c8_resident_blocks(conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, true>, 64 * NW);
+    if (res > 0 && nblk >= (long)res * C8_PERSIST_MIN_TILES) {
+      hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, true>), dim3((unsigned)res), dim3(64 * NW), 0,
+                         stream, p);
+      return check_launch("conv_c8_kernel<persistent>");
+    }
+  }
   hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
   return check_launch("conv_c8_kernel");
 }

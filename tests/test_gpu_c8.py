@@ -152,6 +152,43 @@ def test_ew_add_mask(shape, dtype):
         assert torch.equal(ops.to_nchw(d1).float(), d0.to(dtype).float())
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("hw", [(480, 640), (470, 627)])
+def test_resident_filter_conv3x3_equals_the_staged_kernel(hw, dtype):
+    """Round 4: the plain conv3x3 64->64 of a LARGE launch runs as a persistent kernel with the whole filter resident in LDS
+    (16 waves, 32 x 32 tiles, one workgroup per CU, one barrier per chunk); small launches keep the staged one-tile kernel.
+    Same MFMAs on the same operands in the same order: a batch of 8 (resident form) must equal its four batches of 2 (staged
+    form) bit for bit -- forward with ReLU, and the dgrad epilogues (ReLU mask, accumulate, mask over the sum); ragged image
+    sizes put partial tiles on both edges."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    H, W = hw
+    B = 8
+    x = ops.from_nchw(torch.relu(_rand((B, 64, H, W), 1)).to(dev), dtype)
+    act = ops.from_nchw(_rand((B, 64, H, W), 4).to(dev), dtype)
+    prev = ops.from_nchw(_rand((B, 64, H, W), 5).to(dev), dtype)
+    w = _rand((64, 64, 3, 3), 2, scale=(2.0 / (9 * 64)) ** 0.5).to(dev)
+    wf, wd = ops.packed_weight(w, L.PACK_FWD, dtype), ops.packed_weight(w, L.PACK_DGRAD, dtype)
+    variants = [dict(w=wf, kw=dict(relu=True), init=None),
+                dict(w=wd, kw=dict(relu_mask=True), init=None),
+                dict(w=wd, kw=dict(accumulate=True), init=prev),
+                dict(w=wd, kw=dict(accumulate=True, relu_mask=True, mask_sum=True), init=prev)]
+    for v in variants:
+        def run(lo, hi):
+            xs = x[lo:hi].contiguous()
+            y = (v["init"][lo:hi].clone() if v["init"] is not None else ops.new_act(hi - lo, 64, H, W, dtype, dev).fill_(float("nan")))
+            kw = dict(v["kw"])
+            if kw.get("relu_mask"):
+                kw["relu_mask"] = Slice(act[lo:hi].contiguous())
+            ops.conv2d(Slice(xs), v["w"], Slice(y), 3, **kw)
+            return y
+        full = run(0, B)
+        parts = torch.cat([run(i, i + 2) for i in range(0, B, 2)], 0)
+        assert torch.equal(full, parts), v["kw"]
+        assert not torch.isnan(ops.to_nchw(full).float()).any()
+
+
 @pytest.mark.parametrize("dtype", DT + [torch.float32])
 @pytest.mark.parametrize("k", [3, 5])
 def test_conv_mask_sum_equals_accumulate_then_mask(k, dtype):
