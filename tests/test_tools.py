@@ -12,8 +12,8 @@ HDR = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "T
        "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
        "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 P = 32 * 480 * 640
-K_GATED = "void codon::conv_c8_kernel<codon::C8Bf16, 5, 64, 64, false, 4, true>(codon::ConvC8Params)"
-K_MIXED = "void codon::conv_c8_kernel<codon::C8Bf16, 3, 64, 64, false, 4, false>(codon::ConvC8Params)"
+K_GATED = "void codon::conv_c8_kernel<codon::C8Bf16, 5, 64, 64, false, 4, true, false, false>(codon::ConvC8Params)"
+K_MIXED = "void codon::conv_c8_kernel<codon::C8Bf16, 3, 64, 64, false, 16, false, true, true>(codon::ConvC8Params)"
 K_WG128 = "void codon::conv_wgrad_c8_kernel<codon::C8Bf16, 5, false, 128, 128, false>(codon::WgradC8Params)"
 
 
@@ -43,12 +43,12 @@ def test_pmc_report_joins_per_dispatch_and_rejects_impossible_clocks(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ks = json.load(open(out))["kernels"]
-    g = ks["conv_c8_kernel<C8Bf16, 5, 64, 64, false, 4, true>"]
+    g = ks["conv_c8_kernel<C8Bf16, 5, 64, 64, false, 4, true, false, false>"]
     assert g["launches"] == 8 and g["busy_pass_rejected"] == 1 and "suspect" not in g
     assert abs(g["clock_ghz"] - 1.8) < 1e-6 and abs(g["mfma_busy_frac"] - 0.6) < 1e-6          # the bad dispatch is not averaged in
     assert abs(g["hbm_bytes_per_launch"] - 5.62e9) < 1e3
     assert g["alg_bytes_per_launch"] == (3 * 64 + 64) * 2 * P and "emitted" in g["roles"]       # pre + inputs in, gated + y out
-    m = ks["conv_c8_kernel<C8Bf16, 3, 64, 64, false, 4, false>"]
+    m = ks["conv_c8_kernel<C8Bf16, 3, 64, 64, false, 16, false, true, true>"]
     assert m["roles"] == "mixed" and "traffic_over_alg" not in m                               # fwd + dgrad variants share the name
     w = ks["conv_wgrad_c8_kernel<C8Bf16, 5, false, 128, 128, false>"]
     assert w["alg_bytes_per_launch"] == 256 * 2 * P and abs(w["traffic_over_alg"] - 7.6e9 / (256 * 2 * P)) < 1e-9

@@ -6,6 +6,7 @@
 # One stderr file per command (round 3 wrote five runs into one .err: only the last survived).
 set -e -o pipefail
 tag=${1:-r04}
+# (the box is fresh on every gpurun call; LOCALLY gpurun_out/ accumulates: regenerate tables only from the newest counter CSV per directory)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
