@@ -86,6 +86,9 @@ enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
 #ifndef CODON_C8_NW364
 #define CODON_C8_NW364 4
 #endif
+#ifndef CODON_C8_XEARLY
+#define CODON_C8_XEARLY 1  // resident-filter kernel: request the next chunk's halo tile a whole chunk ahead (0: one / two stages, A/B)
+#endif
 #ifndef CODON_C8_DMA
 #define CODON_C8_DMA 1     // stage x and weights by LDS-DMA (buffer_load_dwordx4 ... lds); 0: through registers (A/B)
 #endif
@@ -351,16 +354,25 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CO
                                                     (int)((unsigned)(CIN / 8) * HW16), C8_RSRC_FLAGS);
         }
       }
+      // RESW: nothing is waited for inside a chunk, so the NEXT chunk's halo tile is requested at the chunk's FIRST stage --
+      // a whole chunk of lead instead of one or two stages.  (Counters on the 3x3 kernels, tools/probes/pmc_conv3.sh: waves
+      // parked at s_waitcnt / barrier 52-55 % of their cycles against 9-13 % in the 5x5 kernels -- with 12 MFMAs per stage a
+      // tile half requested at the start of the chunk's last stage has 0.2 us to cross the memory system.)
+      constexpr bool XEARLY = RESW && CODON_C8_XEARLY != 0;
+      if constexpr (XEARLY && dy == 0) {
+        if (!(par == 1 && c2 + 2 >= NCHUNK)) { LOAD_X(chunk + 1, par ^ 1, 0, XE); }
+        else if (wrap) { LOAD_X(0, par ^ 1, 0, XE); }
+      }
       if (has_next) {
         LOAD_W(s + 1, sbuf ^ 1);
-        if constexpr (dy == KS - 1) LOAD_X(chunk + 1, par ^ 1, XE1, XE);
+        if constexpr (dy == KS - 1 && !XEARLY) LOAD_X(chunk + 1, par ^ 1, XE1, XE);
       } else if constexpr (PERSIST && tail) {
         if (wrap) {
           LOAD_W(0, sbuf ^ 1);
-          LOAD_X(0, par ^ 1, XE1, XE);
+          if constexpr (!XEARLY) LOAD_X(0, par ^ 1, XE1, XE);
         }
       }
-      if constexpr (XE1 > 0 && dy == KS - 2) {
+      if constexpr (XE1 > 0 && dy == KS - 2 && !XEARLY) {
         if (!(par == 1 && c2 + 2 >= NCHUNK)) { LOAD_X(chunk + 1, par ^ 1, 0, XE1); }
         else if constexpr (PERSIST) { if (wrap) LOAD_X(0, par ^ 1, 0, XE1); }
       }
