@@ -34,8 +34,14 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // Debug builds only (make EXTRA=-DCODON_TIMING, tools/exp_timing.py): per-workgroup phase timestamps (100 MHz
 // wall clock) written to the buffer whose address is in the environment variable CODON_DBG_PTR at launch time.
 #ifdef CODON_TIMING
-#define CODON_TSTAMP(dbg_, k_) \
-  if (threadIdx.x == 0 && (dbg_)) (dbg_)[(long)blockIdx.x * 8 + (k_)] = (long long)wall_clock64();
+#define CODON_TSTAMP(dbg_, k_)                                                                          \
+  if (threadIdx.x == 0 && (dbg_)) {                                                                     \
+    (dbg_)[(long)blockIdx.x * 8 + (k_)] = (long long)wall_clock64();                                    \
+    if ((k_) == 0) { /* where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, for per-CU timelines */    \
+      (dbg_)[(long)blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_getreg(0xF804);                  \
+      (dbg_)[(long)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_getreg(0xF814);                  \
+    }                                                                                                   \
+  }
 inline long long* codon_dbg_ptr() {
   const char* e = getenv("CODON_DBG_PTR");
   return e ? (long long*)strtoull(e, nullptr, 16) : nullptr;
