@@ -210,6 +210,12 @@ def test_conv_mask_sum_equals_accumulate_then_mask(k, dtype):
     assert torch.equal(y1, y0)
     frac = float((ops.to_nchw(y1)[:, 64:] == 0).float().mean())
     assert 0.3 < frac < 0.7                                           # the mask did something
+    # ... and against torch: the input gradient of a conv (= transposed conv of gy) added to what was there, then masked
+    to_f = (lambda t: ops.to_nchw(t).float()) if dtype != torch.float32 else (lambda t: t)
+    ref = F.conv_transpose2d(to_f(gy), w.to(dtype).float(), padding=k // 2) + prev[:, 64:]
+    ref = torch.where(to_f(act)[:, :64] > 0, ref, torch.zeros_like(ref))
+    assert rel_rmse(to_f(y1)[:, 64:].cpu(), ref.cpu()) < _tol(dtype)
+    assert torch.equal(to_f(y1)[:, :64], prev[:, :64])                # the other half of the buffer is untouched
 
 
 @pytest.mark.parametrize("dtype", DT + [torch.float32])
@@ -564,6 +570,71 @@ def test_fused_cac_backward_equals_the_apply_pass(shape, dtype, accumulate_in):
             ops.conv1x1_bwd_gated(Slice(r2[fbase]), Slice(g_oc, coff, 64), wc[fbase], Slice(gx1), dw1, gate, fbase, accumulate=acc)
             assert torch.equal(dw1, dw0), (fbase, acc)
             assert torch.equal(gx1, gx0), (fbase, acc)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 33, 70)])
+def test_fused_cac_backward_against_oracle_autograd(shape, dtype):
+    """The round-4 entry points (codon_cac_bwd_reduce_acc, codon_conv1x1_bwd_gated) against torch AUTOGRAD through the
+    oracle's restatement of the block tail (oracle/codon_oracle.py: cac_channel, cac_spatial, the gate-apply of
+    CODON_x4.py:85-91) in float64 -- not against another HIP kernel.  Inputs are 16-bit representable, `pre` is a leaf on
+    both sides (so the arg-max routing of the three max-pools sees identical values), the loss is <g_out, [out | out_c]>:
+        dL/d(inputs)  = g_out (+ what was there);   the five CAC parameter gradients;
+        dL/d(pre)     -> dW = sum_p g_pre (x) r2   and   dL/d(r2) = W^T g_pre * [r2 > 0]   of both 1x1 convs."""
+    from codon_amd import ops
+    from codon_amd import _lib as L
+    from codon_amd.ops import Slice
+    from oracle import codon_oracle as orc
+    dev = _dev()
+    B, H, W = shape
+    q = lambda seed, s=1.0: _rand((B, 128, H, W), seed, s).to(dtype).float()
+    g_oc, pre2, g_in0 = q(1, 0.5), q(2), q(3, 0.5)                 # [depth | colour] halves, as the product lays them out
+    r2 = {64: torch.relu(q(4)), 0: torch.relu(q(5))}               # inputs of confuse (depth, Fcat 64..) / confuse_c (colour)
+    w1, b1, w2 = _rand((8, 128), 7, 0.1), _rand((8,), 8, 0.1), _rand((64, 8), 9, 0.3)
+    b2, ws = _rand((64,), 10, 0.1), _rand((1, 2, 5, 5), 11, 0.2)
+    wconv = {64: _rand((64, 128, 1, 1), 12, 0.1).to(dtype).float(), 0: _rand((64, 128, 1, 1), 13, 0.1).to(dtype).float()}
+
+    # ---- oracle: float64 autograd
+    d64 = lambda t: t.double().clone().requires_grad_(True)
+    pre_l, w1_l, b1_l, w2_l, b2_l, ws_l = d64(pre2), d64(w1), d64(b1), d64(w2), d64(b2), d64(ws)
+    pre_d, pre_c = pre_l[:, :64], pre_l[:, 64:]
+    Fcat = torch.cat((pre_c, pre_d), 1)                                          # :85  colour | depth
+    g = orc.cac_channel(Fcat, w1_l, b1_l, w2_l, b2_l)[:, :, None, None] * orc.cac_spatial(Fcat, ws_l)   # :86-89
+    out = torch.cat((pre_d * g, pre_c * g), 1)                                    # :90-91 without the `+ inputs` leaf
+    (out * g_oc.double()).sum().backward()
+    g_pre = pre_l.grad                                                           # [depth | colour]
+    ref_params = [w1_l.grad, b1_l.grad, w2_l.grad, b2_l.grad, ws_l.grad]
+
+    # ---- HIP: forward statistics / gates (fp32 kernels on the same values), then the fused backward
+    gd = lambda t: ops.from_nchw(t.to(dev), dtype)
+    P2, G, GI = gd(pre2), gd(g_oc), gd(g_in0)
+    pd = lambda t: t.to(dev)
+    nt = ops.cac_stats_tiles(H, W)
+    pooled, partials = torch.empty((B, 2, H, W), device=dev), torch.empty((B, nt, 128, 2), device=dev)
+    ch, sp, pools = torch.empty((B, 64), device=dev), torch.empty((B, 1, H, W), device=dev), torch.empty((B, 2, 128), device=dev)
+    ops.cac_stats(Slice(P2, 64, 64), Slice(P2, 0, 64), pooled, partials)
+    ops.cac_gate(B, H, W, partials, pd(w1), pd(b1), pd(w2), pd(b2), ch, pools)
+    ops.cac_spatial(pooled, pd(ws), sp)
+    *outs, gate = ops.cac_backward_fused(Slice(G, 0, 64), Slice(G, 64, 64), Slice(P2, 0, 64), Slice(P2, 64, 64), ch, sp, pooled,
+                                         pools, pd(w1), pd(b1), pd(w2), pd(ws), Slice(GI, 0, 64), Slice(GI, 64, 64),
+                                         accumulate_in=True)
+    # dL/d(inputs): out = pre * g + inputs  ->  the upstream gradient, added to what the buffer held (one 16-bit rounding)
+    assert torch.equal(ops.to_nchw(GI).float().cpu(), (g_in0 + g_oc).to(dtype).float())
+    for name, a, b in zip(("mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias", "spatial.conv.weight"), outs, ref_params):
+        assert rel_rmse(a.cpu().double(), b) < 1e-4, name
+    for fbase, coff in ((64, 0), (0, 64)):
+        wp = ops.packed_weight(wconv[fbase].to(dev), mode=L.PACK_DGRAD, dtype=dtype)
+        dw = torch.zeros((64, 128, 1, 1), device=dev)
+        gx = ops.new_act(B, 128, H, W, dtype, dev)
+        ops.conv1x1_bwd_gated(Slice(gd(r2[fbase])), Slice(G, coff, 64), wp, Slice(gx), dw, gate, fbase)
+        gp = g_pre[:, coff:coff + 64]
+        dw_ref = torch.einsum("bohw,bihw->oi", gp, r2[fbase].double())
+        gx_ref = torch.einsum("bohw,oi->bihw", gp, wconv[fbase][:, :, 0, 0].double()) * (r2[fbase] > 0)
+        got = ops.to_nchw(gx).float().cpu().double()
+        assert rel_rmse(dw[:, :, 0, 0].cpu().double(), dw_ref) < _tol(dtype), fbase
+        assert rel_rmse(got, gx_ref) < _tol(dtype), fbase
+        # the routed terms are the few large entries of dL/d(pre): a wrong arg-max would show as an O(1) outlier here
+        assert float((got - gx_ref).abs().max()) <= 4 * _tol(dtype) * float(gx_ref.abs().max()) + 1e-6, fbase
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
