@@ -364,6 +364,8 @@ class _CODONBase(nn.Module):
         adt = self._act_dtype()
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or y.dtype != x.dtype:
             raise NotImplementedError(f"codon_amd.CODONNet: input dtype {x.dtype} not supported (fp32, bf16, fp16)")
+        if x.shape[0] == 0:
+            return self._empty_batch(x, y)
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
             if self.conv_precision != "exact":
@@ -385,6 +387,19 @@ class _CODONBase(nn.Module):
                 return codon_apply(self, x, y)
         out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)
         return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+    def _empty_batch(self, x, y):
+        """An empty batch (a rank whose shard of a small global batch holds no image, dist.shard_batch): every op of the
+        reference's forward (CODON_x4.py:66-132) accepts it and returns an empty (0,1,H,W) map whose backward leaves ZERO
+        gradients in the 44 used parameters (None in attention_c5 / attention_s5).  No kernel has anything to do -- the C ABI
+        itself refuses batch 0 -- so the same result is formed here."""
+        out = x.new_zeros(x.shape)
+        if torch.is_grad_enabled():
+            from .autograd import used_parameters
+            live = [p for _, p in used_parameters(self) if p.requires_grad] + [t for t in (x, y) if t.requires_grad]
+            if live:
+                out = out + sum((t.sum() * 0).to(out.dtype) for t in live)
+        return out
 
     def _forward_impl(self, x, y, save: Optional[dict]):
         """Kernel schedule of CODONNet.forward.  With `save` (a dict) every activation the
@@ -629,6 +644,8 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
             raise RuntimeError("codon_amd runs on MI355X only (there is no CPU fallback)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("BaseNet_RMCR_fuseRMCR: inference only; call under torch.no_grad()")
+        if x.shape[0] == 0:
+            return x.new_zeros(x.shape)         # empty batch: an empty map, as the reference's ops return
         idt = x.dtype
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape
@@ -687,6 +704,8 @@ class BaseNet_RMCR_fuseRMCR_cross(_CODONBase):
             raise RuntimeError("codon_amd runs on MI355X only (there is no CPU fallback)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("BaseNet_RMCR_fuseRMCR_cross: inference only; call under torch.no_grad()")
+        if x.shape[0] == 0:
+            return x.new_zeros(x.shape)         # empty batch: an empty map, as the reference's ops return
         idt = x.dtype
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape

@@ -159,3 +159,85 @@ def test_n_rank_hip_gradients_equal_single_process(world):
     bad = {k: v for k, v in res["oracle_err"].items() if not v <= TOL_ORACLE}
     assert not bad, bad
     assert res["oracle_out_rmse"] <= 1e-4
+
+
+def _worker_ragged(rank, world, port, q, B):
+    """Shards of UNEQUAL size, one of them possibly EMPTY (B < world): sum-of-absolute-errors loss normalised by the global
+    element count (a per-shard mean would weight the shards differently), scaled by `world` because all_reduce_grads averages."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        from codon_amd import CODONNet
+        from codon_amd.dist import GradSync, shard_batch
+        from tests.util import target_for
+        torch.manual_seed(5)
+        m = CODONNet().to(dev).train()
+        H, W = 24, 20
+        g = np.random.default_rng(78)
+        x = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32)).to(dev)
+        y = torch.from_numpy(g.uniform(0, 1, size=(B, 1, H, W)).astype(np.float32)).to(dev)
+        t = target_for(x.cpu()).to(dev)
+        gs = GradSync(m)
+        gs.broadcast_parameters(0)
+        lo, hi = shard_batch(B, rank, world)
+        errs = {}
+        for dt in (None, torch.bfloat16):
+            m.set_compute_dtype(dt)
+            gs.zero_grad()
+            out = m(x[lo:hi], y[lo:hi])
+            assert out.shape[0] == hi - lo
+            ((out - t[lo:hi]).abs().sum() * (world / t.numel())).backward()
+            gs.all_reduce_grads()
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                avg = gs.flat.clone()
+                gs.zero_grad()
+                ((m(x, y) - t).abs().sum() / t.numel()).backward()
+                e, off = {}, 0
+                for n, p in gs.named:
+                    k = p.numel()
+                    e[n] = _rel(avg[off:off + k], gs.flat[off:off + k])
+                    off += k
+                errs["bf16" if dt is not None else "f32"] = e
+        dist.barrier()
+        q.put((rank, {"errs": errs, "shard": (lo, hi)} if rank == 0 else {"shard": (lo, hi)}))
+        dist.destroy_process_group()
+    except Exception as e:                                        # noqa: BLE001
+        import traceback
+        q.put((rank, "ERROR: " + "".join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]))
+
+
+@pytest.mark.parametrize("world,B", [(2, 1), (2, 3)])
+def test_ragged_and_empty_shards(world, B):
+    """A global batch that does not divide over the ranks -- with B < world one rank's shard is EMPTY (CODONNet returns an
+    empty map and zero gradients for it, as the reference's forward does) -- still gives the single-process gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q, B)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            r, v = q.get(timeout=600)
+            got[r] = v
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(not (isinstance(v, str) and v.startswith("ERROR")) for v in got.values()), got
+    assert all(p.exitcode == 0 for p in procs)
+    sizes = sorted(got[r]["shard"][1] - got[r]["shard"][0] for r in got)
+    assert sum(sizes) == B and (sizes[0] == 0) == (B < world)
+    for tag in ("f32", "bf16"):
+        e = got[0]["errs"][tag]
+        assert len(e) == 44
+        bad = {k: v for k, v in e.items() if not v <= TOL_SHARD_F32}
+        assert not bad, (tag, bad)

@@ -226,3 +226,37 @@ def test_hipgraph_replay_equals_eager():
     assert gm.stale()
     with pytest.raises(RuntimeError, match="changed after capture"):
         gm(x, y)
+
+
+@pytest.mark.parametrize("variant", ["x4", "x16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_empty_batch(variant, dtype):
+    """An empty batch (a rank whose shard of a small global batch holds no image): like the reference's forward
+    (tests/test_oracle.py::test_empty_batch_and_tiny_images pins that on the oracle) the module returns an empty (0,1,H,W)
+    map; its backward leaves zero gradients in the 44 used parameters and None in the unused attention_*5."""
+    from codon_amd import BaseNet_RMCR_fuseRMCR
+    m = _model(variant, orc.he_state(variant, seed=3))
+    if dtype != torch.float32:
+        m.set_compute_dtype(dtype)
+    e = torch.zeros((0, 1, 12, 10), device="cuda", dtype=dtype)
+    with torch.no_grad():
+        o = m(e, e)
+    assert tuple(o.shape) == (0, 1, 12, 10) and o.dtype == dtype and o.is_cuda
+    m.train()
+    o = m(e, e)
+    assert tuple(o.shape) == (0, 1, 12, 10) and o.requires_grad
+    o.sum().backward()
+    n_zero = 0
+    for k, p_ in m.named_parameters():
+        if k.startswith(("attention_c5", "attention_s5")):
+            assert p_.grad is None, k
+        else:
+            assert p_.grad is not None and float(p_.grad.abs().max()) == 0.0, k
+            n_zero += 1
+    assert n_zero == 44
+    # the next real batch is unaffected
+    x = torch.rand((1, 1, 12, 10), device="cuda", dtype=dtype)
+    with torch.no_grad():
+        assert bool(torch.isfinite(m.eval()(x, x)).all())
+        r = BaseNet_RMCR_fuseRMCR().cuda().eval()
+        assert tuple(r(e.float(), e.float()).shape) == (0, 1, 12, 10)

@@ -145,3 +145,27 @@ def test_forced_relu_masks_reproduce_the_plain_forward():
     with torch.no_grad():
         out = orc.forward(sd, x, y, masks=seen)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("variant", ["x4", "x16"])
+def test_empty_batch_and_tiny_images(variant):
+    """Edge cases of the reference's forward that the product has to mirror: an empty batch gives an empty (0,1,H,W) map
+    whose backward leaves ZERO gradients in every used parameter and None in the unused attention_*5 (x4); 1 x 1 and 2 x 3
+    images run (every conv pads, both pools cover the whole image)."""
+    sd = {k: v.clone().requires_grad_(True) for k, v in orc.he_state(variant, seed=3).items()}
+    e = torch.zeros((0, 1, 12, 10))
+    out = orc.forward(sd, e, e)
+    assert tuple(out.shape) == (0, 1, 12, 10)
+    out.sum().backward()
+    used = [k for k in sd if not k.startswith(("attention_c5", "attention_s5"))]
+    assert len(used) == 44
+    for k in used:
+        assert sd[k].grad is not None and float(sd[k].grad.abs().max()) == 0.0, k
+    for k in sd:
+        if k not in used:
+            assert sd[k].grad is None, k
+    with torch.no_grad():
+        for shape in ((1, 1, 1, 1), (2, 1, 2, 3)):
+            x = torch.rand(shape)
+            o = orc.forward(sd, x, x.flip(0))
+            assert o.shape == x.shape and bool(torch.isfinite(o).all())
