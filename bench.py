@@ -190,7 +190,8 @@ def script_pattern_latency(dev):
     return res
 
 
-def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype, scale, scaling="weak"):
+def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype, scale, scaling="weak", ctrl=None,
+              data=None):
     """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP
     dgrad/wgrad/CAC kernels), ONE all-reduce of the flat gradient buffer (RCCL when world > 1), Adam step.
     Nothing is skipped.  Returns the result dict on rank 0 (None elsewhere)."""
@@ -198,7 +199,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
     from codon_amd.metrics import L1SSIMLoss
     B, _, H, W = x.shape
     model.train()
-    gs = GradSync(model)
+    gs = GradSync(model, process_group=data)     # the gradient all-reduce: RCCL (default group) unless the probe failed
     gs.broadcast_parameters(0)
     opt = torch.optim.Adam(gs.params, lr=1e-4)
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
@@ -244,11 +245,8 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             gs.all_reduce_grads()
         torch.cuda.synchronize(dev)
         ar_us = (time.perf_counter() - t1) / 10 * 1e6
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    per_rank = gather_rank_info(step_stats(evs), dist, rank, world)
+    dt = max_over_ranks(dt, dist, ctrl)
+    per_rank = gather_rank_info(step_stats(evs), dist, rank, world, ctrl)
     model.check_packed(synchronize=False)
     if rank != 0:
         return None
@@ -376,12 +374,45 @@ def rank_info(dev, local):
             os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
 
 
-def gather_rank_info(info, dist, rank, world):
+def gather_rank_info(info, dist, rank, world, ctrl=None):
     if dist is None:
         return [info]
     out = [None] * world
-    dist.all_gather_object(out, info)
+    dist.all_gather_object(out, info, group=ctrl)
     return out
+
+
+def max_over_ranks(v, dist, ctrl=None):
+    """The contract's MAX over ranks of a host-side time: a CPU tensor on the control group."""
+    if dist is None:
+        return float(v)
+    t = torch.tensor([v], dtype=torch.float64)
+    if ctrl is None and dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctrl)
+    return float(t.item())
+
+
+def rccl_probe(dist, dev, world, ctrl):
+    """First RCCL collective of the run: one all-reduce of a single element on the default (RCCL) group -- this is where
+    the communicator over xGMI is formed.  Never fatal: the forward has no data-path collective, so when RCCL cannot form
+    a communicator (or returns a wrong sum) the run continues with every collective on the gloo control group and the line
+    says so (`rccl_probe.ok` false, `backend` "gloo").  All ranks take the same decision (MIN over the control group)."""
+    t0 = time.perf_counter()
+    ok, err, got = False, None, None
+    try:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(dev)
+        got = float(t.item())
+        ok = abs(got - world) < 1e-6
+        if not ok:
+            err = f"all_reduce(1) over {world} ranks returned {got}"
+    except Exception as e:              # noqa: BLE001 -- reported in the line
+        err = f"{type(e).__name__}: {e}"[:600]
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctrl)
+    return {"ok": bool(flag.item() == 1.0), "this_rank_ok": ok, "error": err, "ms": (time.perf_counter() - t0) * 1e3}
 
 
 def software_versions(backend):
@@ -441,15 +472,26 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1) if a.backend == "gloo" else local   # rehearsal: ranks may share a GPU
+    share = a.backend == "gloo" or os.environ.get("CODON_BENCH_SHARE_GPU") == "1"   # rehearsal: ranks may share a GPU
+    local = local % max(ndev, 1) if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist = ctrl = data = probe = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL
+            # Default group = RCCL (its communicator forms at the first GPU collective: rccl_probe).  The CONTROL plane --
+            # the barriers around the timed region, the max over ranks, the rank records -- runs on a gloo group beside
+            # it: the forward shards images and has no data-path collective, so its measurement must not depend on the
+            # health of a fabric it does not use.  Training's gradient all-reduce and the self-check go through RCCL.
+            dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=int(os.environ.get("CODON_RCCL_TIMEOUT_S", "600"))))
+            ctrl = dist.new_group(backend="gloo")
+            probe = rccl_probe(dist, dev, world, ctrl)
+            data = None if probe["ok"] else ctrl
+            if not probe["ok"] and rank == 0:
+                print(f"bench.py: RCCL probe failed ({probe['error']}); collectives fall back to gloo", file=sys.stderr)
         else:
             dist.init_process_group("gloo")
 
@@ -461,11 +503,11 @@ def main():
         # the line is still printed, with grad_equal false and the reason)
         from codon_amd.dist import grad_equality_selfcheck
         try:
-            selfcheck = grad_equality_selfcheck(dev)
+            selfcheck = grad_equality_selfcheck(dev, group=data)
         except Exception as e:          # noqa: BLE001
             selfcheck = {"grad_equal": False, "error": f"{type(e).__name__}: {e}"[:500]}
         torch.cuda.empty_cache()
-    ranks = gather_rank_info(rank_info(dev, local), dist, rank, world)
+    ranks = gather_rank_info(rank_info(dev, local), dist, rank, world, ctrl)
     versions = software_versions(a.backend if world > 1 else None)
     torch.manual_seed(0)
     rmcr = a.model == "rmcr"
@@ -485,20 +527,25 @@ def main():
     def barrier():
         torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctrl)
         torch.cuda.synchronize(dev)
 
     if a.mode == "train":
-        res = train_leg(model, x, y, dev, dist, rank, world, barrier, a.steps, a.warmup, a.dtype, a.scale, a.scaling)
+        res = train_leg(model, x, y, dev, dist, rank, world, barrier, a.steps, a.warmup, a.dtype, a.scale, a.scaling,
+                        ctrl=ctrl, data=data)
         if rank == 0:
             for r_, st_ in zip(ranks, res["per_rank_step_ms"]):
                 r_["train_step_ms"] = st_
             res["ranks"], res["versions"] = ranks, versions
+            res["backend"] = None if dist is None else ("gloo" if (a.backend == "gloo" or data is not None) else "nccl")
+            res["control_backend"] = None if dist is None else "gloo"
+            if probe is not None:
+                res["rccl_probe"] = probe
             if selfcheck is not None:
                 res["grad_equal"], res["rccl_selfcheck"] = selfcheck["grad_equal"], selfcheck
             print(json.dumps(res), flush=True)
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctrl)
             dist.destroy_process_group()
         return
 
@@ -522,11 +569,8 @@ def main():
         prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out).all()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    fwd_per_rank = gather_rank_info(step_stats(step_ev), dist, rank, world)   # a straggler GPU shows up per rank
+    dt = max_over_ranks(dt, dist, ctrl)
+    fwd_per_rank = gather_rank_info(step_stats(step_ev), dist, rank, world, ctrl)   # a straggler GPU shows up per rank
 
     res = None
     if rank == 0:
@@ -590,7 +634,12 @@ def main():
                 "rmse_vs_exact_fp32_output": dev_rmse, "output_std": float(out.double().std()),
                 "parity": "passes the same RMSE <= 1e-4 fixtures as the exact path (tests/test_gpu_f16x3.py)"}
         res["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
-        res["backend"] = (dist.get_backend() if dist is not None else None)
+        # `backend`: what the data-path collectives (training's gradient all-reduce, the self-check) run on; the control
+        # plane (barriers, max over ranks, rank records) is gloo whenever RCCL is the data backend
+        res["backend"] = None if dist is None else ("gloo" if (a.backend == "gloo" or data is not None) else "nccl")
+        res["control_backend"] = None if dist is None else "gloo"
+        if probe is not None:
+            res["rccl_probe"] = probe
         for r_, st_ in zip(ranks, fwd_per_rank):
             r_["fwd_step_ms"] = {k: st_[k] for k in ("median_ms", "min_ms", "max_ms")} if st_ else None
         res["ranks"], res["versions"] = ranks, versions
@@ -616,7 +665,7 @@ def main():
         tm = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev)
         tm.set_compute_dtype(torch.bfloat16)
         tsteps = 10 if (B, H, W) == (32, 480, 640) else max(3, min(a.steps, 10))     # >= 10 timed iterations
-        leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 2, "bf16", a.scale, a.scaling)
+        leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 2, "bf16", a.scale, a.scaling, ctrl=ctrl, data=data)
         del tm
         torch.cuda.empty_cache()
         if rank == 0:
@@ -640,7 +689,7 @@ def main():
                     res["script_pattern_on_gpu"] = script_pattern_latency(dev)
         print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctrl)
         dist.destroy_process_group()
 
 

@@ -91,17 +91,18 @@ def shard_batch(n_images: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5):
+def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5, group: Optional[dist.ProcessGroup] = None):
     """First-contact check of the data-parallel path on whatever backend the process group runs (RCCL over xGMI on the
     8-GPU node; gloo in rehearsals): SURVEY.md 8(e)'s correctness test on the product kernels, small enough to run before
     every multi-rank benchmark.  Ranks build DIFFERENT parameters, rank 0's are broadcast, every rank runs the HIP forward
     + backward on ITS image of a world-sized batch (per-image-mean L1 loss), one all-reduce of the flat gradient; then
     each rank computes the gradient of the whole batch by itself and compares, in fp32 and in bf16.  Returns
-    {"grad_equal": bool over all ranks, "worst_rel": {dtype: max over tensors and ranks}, "first_forward_equal": bool}."""
+    {"grad_equal": bool over all ranks, "worst_rel": {dtype: max over tensors and ranks}, "first_forward_equal": bool}.
+    group: the process group the gradients travel on (None = the default group)."""
     import numpy as np
     from .model import CODONNet
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     H, W = size
     rng = np.random.default_rng(4242)
     x = torch.from_numpy(rng.uniform(0, 1, size=(world, 1, H, W)).astype(np.float32)).to(device)
@@ -113,7 +114,7 @@ def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5):
     torch.random.set_rng_state(state)
     with torch.no_grad():
         m(x[:1], y[:1])                                   # packs this rank's OWN weights: the broadcast must drop them
-    gs = GradSync(m)
+    gs = GradSync(m, process_group=group)
     gs.broadcast_parameters(0)
     worst, ok = {}, True
     with torch.no_grad():
@@ -121,8 +122,8 @@ def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5):
     digest = torch.stack([o.double().sum(), o.double().abs().sum(), o.double().pow(2).sum()])
     lo_, hi_ = digest.clone(), digest.clone()
     if world > 1:
-        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
     first_equal = bool(torch.equal(lo_, hi_))
     for dt, tag in ((None, "f32"), (torch.bfloat16, "bf16")):
         m.set_compute_dtype(dt)
@@ -140,7 +141,7 @@ def grad_equality_selfcheck(device, size=(24, 20), tol: float = 2e-5):
             off += n
         wt = torch.tensor([w], dtype=torch.float64, device=device)
         if world > 1:
-            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX, group=group)
         worst[tag] = float(wt.item())
         ok = ok and worst[tag] <= tol and bool(torch.isfinite(avg).all())
     m.check_packed()

@@ -50,6 +50,26 @@ def test_bench_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_survives_an_rccl_that_cannot_form_a_communicator():
+    """--backend nccl with two ranks on the ONE GPU of the box: RCCL refuses (duplicate device).  That is this pool's only
+    way to exercise the failure path of the 8-GPU run's first RCCL collective: the probe reports it, every collective moves
+    to the gloo control group, and the line -- forward throughput, self-check, training leg -- is still printed."""
+    env = dict(os.environ, CODON_BENCH_SHARE_GPU="1", CODON_RCCL_TIMEOUT_S="120")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96"], capture_output=True, text=True,
+                       timeout=900, env={k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["rccl_probe"]["ok"] is False and d["rccl_probe"]["error"], d["rccl_probe"]
+    assert d["backend"] == "gloo" and d["control_backend"] == "gloo"
+    assert d["grad_equal"] is True, d.get("rccl_selfcheck")          # the data path itself is sound: on gloo it agrees
+    assert d["fwd_bwd"]["rccl_ranks"] == 2
+
+
+@pytest.mark.gpu
 def test_bench_four_ranks_strong_scaling_and_diagnostics():
     """4 self-launched ranks sharing the one GPU (gloo rehearsal of the 8-GPU run), --scaling strong: 8 images IN TOTAL,
     2 per rank; rank 0's line carries what a mis-bound multi-GPU run would need to be diagnosed from the record alone."""
