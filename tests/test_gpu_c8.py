@@ -514,6 +514,9 @@ def test_conv1x1_bwd_equals_wgrad_plus_masked_dgrad(shape, dtype):
         assert torch.isnan(got[:, :64]).all() and torch.isnan(got[:, 192:]).all()
     ref = torch.einsum("bohw,oi->bihw", ops.to_nchw(g)[:, 64:].float(), w[:, :, 0, 0]) * (ops.to_nchw(x)[:, 64:] > 0)
     assert rel_rmse(ops.to_nchw(gx0).float().cpu(), ref.cpu()) < _tol(dtype)
+    # dW against torch in float64 on the same 16-bit values: written once (accumulate=False), then added once more
+    dw_ref = 2 * torch.einsum("bohw,bihw->oi", ops.to_nchw(g)[:, 64:].double(), ops.to_nchw(x)[:, 64:].double())
+    assert rel_rmse(dw1[:, :, 0, 0].double().cpu(), dw_ref.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("dtype", DT)
