@@ -481,6 +481,9 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+            # one node by contract: keep gloo off the container hostname (it may not resolve) and on the loopback device
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if a.backend == "nccl":
             # Default group = RCCL (its communicator forms at the first GPU collective: rccl_probe).  The CONTROL plane --
             # the barriers around the timed region, the max over ranks, the rank records -- runs on a gloo group beside
