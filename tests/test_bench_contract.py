@@ -70,6 +70,28 @@ def test_bench_survives_an_rccl_that_cannot_form_a_communicator():
 
 
 @pytest.mark.gpu
+def test_bench_under_the_drivers_torchrun_line():
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher.
+    Two ranks sharing the one GPU, gloo (the RCCL-refuses variant of the same launch is the test above)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend",
+                        "gloo", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96",
+                        "--no-fwd-bwd"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["grad_equal"] is True
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["local_rank"] for x in d["ranks"]] == [0, 0]
+
+
+@pytest.mark.gpu
 def test_bench_four_ranks_strong_scaling_and_diagnostics():
     """4 self-launched ranks sharing the one GPU (gloo rehearsal of the 8-GPU run), --scaling strong: 8 images IN TOTAL,
     2 per rank; rank 0's line carries what a mis-bound multi-GPU run would need to be diagnosed from the record alone."""
