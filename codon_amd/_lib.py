@@ -51,6 +51,7 @@ SIGNATURES = {
     "codon_conv_packed_weight_bytes": (_S, [_I, _I, _I, _I]),
     "codon_conv_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "codon_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "codon_conv2d_sum_into_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "codon_conv_chain1x1_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P]),
     "codon_conv_chain1x1_stats_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P, _P, _I, _P]),
     "codon_cac_fused_tiles": (_I, [_I, _I]),

@@ -32,6 +32,10 @@ MASK_IN_EPILOGUE = _os.environ.get("CODON_MASK_IN_EPILOGUE", "1") != "0"
 # 16-bit: the CAC gate backward without its apply pass -- dL/d(pre) is formed in the staging of the 1x1 backward that
 # consumes it, dL/d(inputs) accumulates in the reduce pass (ops.cac_backward_fused); 0 = the four-kernel form (A/B)
 FUSED_CAC_BWD = _os.environ.get("CODON_FUSED_CAC_BWD", "1") != "0"
+# ... and dL/d(inputs) += dL/d(out_i) taken in the epilogue of the LAST dgrad conv that forms dL/d(out_i) (a conv5x5 64->64 in
+# both streams: matrix-bound, the extra 2.5 GB ride along) instead of in the HBM-bound reduce pass (ops.conv2d_sum_into);
+# 0 = in the reduce pass (A/B).  Bit-identical either way.
+SUM_IN_DGRAD = _os.environ.get("CODON_SUM_IN_DGRAD", "1") != "0"
 
 # parameters in a fixed order: the flat gradient buffer of codon_amd.dist uses the same order
 _CONVS = ["input", "conv_input", "conv1", "conv2", "conv3", "confuse", "input_c", "conv_input_c", "conv4", "conv5",
@@ -180,6 +184,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     in2 = S["in2"]
     g_in2 = new(128)                                # running dL/d[inputs | inputs_c]
     g_pre2 = None if fused_cac else new(128)
+    sum_in = fused_cac and SUM_IN_DGRAD             # dL/d(inputs) += dL/d(out_{i-1}) by block i's last dgrads
     for i in (4, 3, 2, 1, 0):
         Bk = S[f"blk{i}"]
         xin, r2, r2_c, pre2 = Bk["x"], Bk["r2"], Bk["r2_c"], Bk["pre2"]
@@ -193,7 +198,8 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             dw1, db1, dw2, db2, dws, gate = ops.cac_backward_fused(
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
                 Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
-                f32(asp.spatial.conv.weight), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64), accumulate_in=(i != 4))
+                f32(asp.spatial.conv.weight), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
+                accumulate_in=((0 if i == 4 else 2) if sum_in else (i != 4)))
         else:
             dw1, db1, dw2, db2, dws = ops.cac_backward(
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
@@ -224,7 +230,10 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         last0 = dict(relu_mask=Slice(in2, 0, 64), mask_sum=True) if (i == 0 and MASK_IN_EPILOGUE) else {}
         last1 = dict(relu_mask=Slice(in2, 64, 64), mask_sum=True) if (i == 0 and MASK_IN_EPILOGUE) else {}
         ops.conv2d(Slice(g_stage, 0, 64), Pd("conv1"), Slice(g_x, 0, 64), 3, accumulate=acc0)
-        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True, **last0)
+        if sum_in and i > 0:      # g_x = dL/d(out_{i-1}) is complete with this launch: it also goes into dL/d(inputs)
+            ops.conv2d_sum_into(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, Slice(g_in2, 0, 64), accumulate=True)
+        else:
+            ops.conv2d(Slice(g_stage, 64, 64), Pd("conv2"), Slice(g_x, 0, 64), 5, accumulate=True, **last0)
         # colour stream: stage_c = [relu(conv4(x_c)) 5x5 | relu(conv5(x_c)) 3x3]
         stage_c = restage(Bk["stage_c"], Slice(xin, 64, 64), ("conv4", 5), ("conv5", 3))
         if gate is not None:
@@ -235,8 +244,12 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_r2), Pd("conv6"), Slice(g_stage), 5, relu_mask=Slice(stage_c))
         wgrad("conv4", Slice(xin, 64, 64), Slice(g_stage, 0, 64), 5)
         wgrad("conv5", Slice(xin, 64, 64), Slice(g_stage, 64, 64), 3)
-        ops.conv2d(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, accumulate=acc0)
-        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv5"), Slice(g_x, 64, 64), 3, accumulate=True, **last1)
+        # (the conv3x3 first, so that the stream's LAST input gradient is the matrix-bound conv5x5, as in the depth stream)
+        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv5"), Slice(g_x, 64, 64), 3, accumulate=acc0)
+        if sum_in and i > 0:
+            ops.conv2d_sum_into(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, Slice(g_in2, 64, 64), accumulate=True)
+        else:
+            ops.conv2d(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, accumulate=True, **last1)
     del g_oc, g_pre2, g_r2, g_stage
 
     # ---- heads: in2 = [relu(conv_input(stem)) | relu(conv_input_c(stem_c))]            :68-72

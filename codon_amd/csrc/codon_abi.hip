@@ -85,6 +85,7 @@ int cac_stats_tiles(int, int);
 int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t, const float*);
 int ew_sq_scale(int, int, int, const codon_tensor*, const float*, const codon_tensor*, int, hipStream_t);
 int conv2d_fwd_bf16(const codon_conv_desc*, const void*, const void*, void*, const void*, hipStream_t);
+int conv2d_sum_into_16(const codon_conv_desc*, const void*, const void*, void*, void*, hipStream_t);
 int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int cac_gate_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
                  hipStream_t);
@@ -191,6 +192,21 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
   }
   return conv2d_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)residual,
                         (hipStream_t)stream);
+}
+
+int codon_conv2d_sum_into_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y, void* sum,
+                              codon_stream_t stream) {
+  CODON_REQUIRE(d && x && w_packed && y && sum, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: bad shape %dx%dx%d",
+                d->batch, d->height, d->width);
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal &&
+                    d->r_coff >= 0 && d->r_coff + d->cout <= d->r_ctotal,
+                CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: channel slice outside its buffer");
+  CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: packed weights not 16-byte aligned");
+  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
+                "conv2d_sum_into_fwd: 16-bit dtypes only (dtype %d)", d->dtype);
+  CODON_REQUIRE(sum != y && sum != x, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: sum aliases x or y");
+  return conv2d_sum_into_16(d, x, w_packed, y, sum, (hipStream_t)stream);
 }
 
 int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y, const void* w_chain,

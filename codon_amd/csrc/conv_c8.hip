@@ -67,7 +67,10 @@ __device__ __forceinline__ float relu1_c8(float v) {   // one v_max (fmaxf adds 
   return o;
 }
 
-enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2 };
+enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2, RESC8_SUMINTO = 3 };
+// internal flag bit (never part of the ABI's CODON_CONV_* set): p.res is a READ-WRITE running sum that takes the value this
+// launch stores, sum += y, in the same epilogue (codon_conv2d_sum_into_fwd; conv5x5 64->64 only)
+constexpr int CONV_C8_SUM_INTO = 1 << 16;
 
 // pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is
 // 8 MFMAs on 6 operand fetches
@@ -630,7 +633,17 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CO
             if constexpr (RES == RESC8_MASK && MS) v = r8[j] > 0.f ? v : 0.f;
             v8[j] = v;
           }
-          c8_st(c8_pack<E>(v8), yrsrc, vo[i], cplane(t, g));
+          const u32x4 q = c8_pack<E>(v8);
+          c8_st(q, yrsrc, vo[i], cplane(t, g));
+          if constexpr (RES == RESC8_SUMINTO) {
+            // sum += the value AS STORED (one 16-bit rounding each): the arithmetic of the pass this replaces
+            // (cac_bwd_reduce_acc: g_inputs += g_out read back from HBM)
+            float y8[8];
+            c8_unpack<E>(q, y8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] += y8[j];
+            c8_st(c8_pack<E>(r8), rrsrc, vo[i], cplane(t, g));
+          }
         }
       }
     }
@@ -640,6 +653,15 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CO
   using R0 = std::integral_constant<int, RESC8_NONE>;
   using R1 = std::integral_constant<int, RESC8_ADD>;
   using R2 = std::integral_constant<int, RESC8_MASK>;
+  constexpr bool HAS_SUMINTO = KS == 5 && CIN == 64 && COUT == 64 && !FUSE && !GATE && !PERSIST;
+  if constexpr (HAS_SUMINTO) {
+    if (p.res && (p.flags & CONV_C8_SUM_INTO)) {          // wave-uniform
+      using R3 = std::integral_constant<int, RESC8_SUMINTO>;
+      if (p.flags & CODON_CONV_ACCUM_OUT) epi(F{}, R3{}, T{}, F{});
+      else epi(F{}, R3{}, F{}, F{});
+      break;
+    }
+  }
   const int res_mode = !p.res ? RESC8_NONE : (p.flags & CODON_CONV_MASK_RELU) ? RESC8_MASK
                                            : (p.flags & CODON_CONV_ADD_RESIDUAL) ? RESC8_ADD : RESC8_NONE;
   const bool accum = p.flags & CODON_CONV_ACCUM_OUT;
@@ -991,6 +1013,33 @@ int conv2d_fwd_bf16(const codon_conv_desc* d, const void* x, const void* w, void
                 "conv2d_fwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
   return d->dtype == CODON_F16 ? conv2d_fwd_c8<C8F16>(d, x, w, y, with_res ? res : nullptr, stream)
                                : conv2d_fwd_c8<C8Bf16>(d, x, w, y, with_res ? res : nullptr, stream);
+}
+
+// y (+)= conv5x5(x) (64 -> 64) and, in the same epilogue, sum += y
+int conv2d_sum_into_16(const codon_conv_desc* d, const void* x, const void* w, void* y, void* sum, hipStream_t stream) {
+  CODON_REQUIRE(d->ksize == 5 && d->cin == 64 && d->cout == 64, CODON_ERR_UNSUPPORTED,
+                "conv2d_sum_into_fwd: the 16-bit conv5x5 64->64 only (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
+  CODON_REQUIRE((d->flags & ~CODON_CONV_ACCUM_OUT) == 0, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: only ACCUM_OUT applies");
+  CODON_REQUIRE(c8_desc_ok(d, true), CODON_ERR_BAD_ARG,
+                "conv2d_sum_into_fwd: 16-bit tensors are channel-blocked: ctotal / coff / channels must be multiples of 8");
+  const long HW = (long)d->height * d->width;
+  CODON_REQUIRE(HW * 2 * 128 < (long)C8_OOB, CODON_ERR_UNSUPPORTED,
+                "conv2d_sum_into_fwd: %dx%d image: 128 channels exceed the 4 GiB buffer-descriptor range", d->height, d->width);
+  ConvC8Params p;
+  c8_fill(p, d, x, w, y, sum);
+  p.flags |= CONV_C8_SUM_INTO;
+  // the plain one-tile-per-workgroup kernel (the variant is not compiled into the tile-loop forms)
+  constexpr int NW = ConvC8Nw<5, 64>::value, TH = NW * ConvC8Pseg<5, 64>::value;
+  p.tiles_x = (d->width + 31) / 32;
+  p.tiles_y = (d->height + TH - 1) / TH;
+  const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_sum_into_fwd: grid too large (%ld blocks)", nblk);
+  p.nblk = (int)nblk;
+  if (d->dtype == CODON_F16)
+    hipLaunchKernelGGL((conv_c8_kernel<C8F16, 5, 64, 64, false, NW, false>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_c8_kernel<C8Bf16, 5, 64, 64, false, NW, false>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
+  return check_launch("conv_c8_kernel<sum into>");
 }
 
 int conv_chain1x1_fwd_16(const codon_conv_desc* d, const void* x, const void* w, void* y, const void* w_chain,

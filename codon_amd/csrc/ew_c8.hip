@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
         qgc[kk] = c8_ld(r_gc, vo[kk], so);
         qp[kk] = c8_ld(r_p, vo[kk], so);
         qpc[kk] = c8_ld(r_pc, vo[kk], so);
-        if (accumulate_in) { qi[kk] = c8_ld(r_gi, vo[kk], so); qic[kk] = c8_ld(r_gic, vo[kk], so); }
+        if (accumulate_in == 1) { qi[kk] = c8_ld(r_gi, vo[kk], so); qic[kk] = c8_ld(r_gic, vo[kk], so); }
       }
 #pragma unroll
       for (int kk = 0; kk < KH; ++kk) {
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
         }
         st_gsp[k][tid] = gsp;
         st_acd[k][tid] = acd;
-        if (accumulate_in) {               // g_inputs (+)= g_out, the arithmetic of cac_bwd_apply_c8_kernel
+        if (accumulate_in == 1) {          // g_inputs (+)= g_out, the arithmetic of cac_bwd_apply_c8_kernel
           float gi[8], gic[8];
           c8_unpack<E>(qi[kk], gi);
           c8_unpack<E>(qic[kk], gic);
@@ -812,10 +812,10 @@ __global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
           for (int j = 0; j < 8; ++j) { gi[j] = gi[j] + go[j]; gic[j] = gic[j] + gc[j]; }
           c8_st(c8_pack<E>(gi), r_gi, vo[kk], so);
           c8_st(c8_pack<E>(gic), r_gic, vo[kk], so);
-        } else {
+        } else if (accumulate_in == 0) {
           c8_st(qgo[kk], r_gi, vo[kk], so);
           c8_st(qgc[kk], r_gic, vo[kk], so);
-        }
+        }                                  // 2: dL/d(inputs) already holds this block's dL/d(out) (codon_conv2d_sum_into_fwd)
       }
     }
 #pragma unroll

@@ -169,6 +169,30 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
             prof["events"].append((e0, e1))
 
 
+def conv2d_sum_into(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, total: Slice, accumulate: bool = False):
+    """16-bit, conv5x5 64 -> 64: y (+)= conv(x) and, in the same epilogue, total += y (the stored value): the last input
+    gradient that fans into a block's dL/d(out) also feeds the running dL/d(inputs) (codon_conv2d_sum_into_fwd)."""
+    lib = L.load()
+    dev = _dev(x.buf, w_packed, y.buf, total.buf)
+    B, H, W = _bhw(x.buf)
+    assert _bhw(y.buf) == (B, H, W) == _bhw(total.buf) and total.c == y.c and is_c8(x.buf.dtype)
+    assert total.buf.dtype == y.buf.dtype == x.buf.dtype
+    # total may live in the same ALLOCATION as nothing else here: it must not overlap y or x
+    assert total.buf.data_ptr() not in (y.buf.data_ptr(), x.buf.data_ptr())
+    d = L.ConvDesc(B, H, W, x.c, y.c, ksize, x.ctotal, x.coff, y.ctotal, y.coff, total.ctotal, total.coff,
+                   L.CONV_ACCUM_OUT if accumulate else 0, _dt(x.buf))
+    prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
+    with torch.cuda.device(dev):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+        L.check(lib.codon_conv2d_sum_into_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed), _ptr(y.buf), _ptr(total.buf),
+                                              _stream(dev)), "conv2d_sum_into_fwd")
+        if prof is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            prof["events"].append((e0, e1))
+
+
 def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: Slice, mid: Optional[Slice] = None,
                   residual: Optional[Slice] = None, f16x3: bool = False, stats=None):
     """out = conv1x1(relu(conv5x5(x))) [+ residual] in one launch (the 1x1 runs from the 5x5's accumulators);
@@ -485,7 +509,8 @@ def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, c
                        g_in: Slice, g_in_c: Slice, accumulate_in: bool):
     """16-bit tensors, training: the CAC gate backward WITHOUT the apply pass.  Pass A also records every pixel's arg-max
     channel and folds g_out into g_in (codon_cac_bwd_reduce_acc); dL/d(pre) is not materialised -- conv1x1_bwd_gated forms
-    it from g_out while staging.  Returns (dw1, db1, dw2, db2, dws, gate) with gate = the operands conv1x1_bwd_gated needs."""
+    it from g_out while staging.  Returns (dw1, db1, dw2, db2, dws, gate) with gate = the operands conv1x1_bwd_gated needs.
+    accumulate_in: False / 0 = g_in := g_out, True / 1 = g_in += g_out, 2 = g_in untouched (conv2d_sum_into did it)."""
     lib = L.load()
     dev = _dev(g_out.buf, g_out_c.buf, pre.buf, pre_c.buf, ch, sp, pooled, pools, w1, b1, w2, ws, g_in.buf, g_in_c.buf)
     assert is_c8(pre.buf.dtype)
@@ -511,7 +536,7 @@ def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, c
     with torch.cuda.device(dev):
         L.check(lib.codon_cac_bwd_reduce_acc(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]), _ptr(ch),
                                              _ptr(sp), _ptr(pools), _ptr(pooled), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
-                                             _ptr(argch), C.byref(t[4]), C.byref(t[5]), 1 if accumulate_in else 0,
+                                             _ptr(argch), C.byref(t[4]), C.byref(t[5]), int(accumulate_in),
                                              _dt(pre.buf), st), "cac_bwd_reduce_acc")
         L.check(lib.codon_cac_bwd_gate(B, H, W, _ptr(part_gch), _ptr(part_arg), _ptr(ch), _ptr(pools), _ptr(w1),
                                        _ptr(b1), _ptr(w2), _ptr(g_pools), _ptr(argpix), _ptr(part_param), _ptr(dw1),

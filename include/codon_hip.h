@@ -104,6 +104,15 @@ int codon_conv_pack_weight(const float* w_oihw, void* w_packed, int32_t cout, in
 int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
                      const void* residual, codon_stream_t stream);
 
+/* 16-bit tensors, conv5x5 64 -> 64 (training, round 4):  y (+)= conv(x)  exactly as codon_conv2d_fwd with flags 0 /
+ * CODON_CONV_ACCUM_OUT, and in the same epilogue   sum += y   with y the value AS STORED (so the result equals a separate
+ * pass that reads y back, bit for bit).  d->r_ctotal / r_coff describe `sum` (READ-WRITE).  Used for the LAST input
+ * gradient that fans into a block's dL/d(out): the running dL/d(inputs) of the network's long skip connection
+ * (`out*g + inputs`, /root/reference/CODON_X4/CODON_x4.py:90-91,117-118) takes it there instead of in a pass of its own
+ * (codon_cac_bwd_reduce_acc with accumulate_in = 2). */
+int codon_conv2d_sum_into_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y, void* sum,
+                              codon_stream_t stream);
+
 /* conv5x5(128 -> 128) + ReLU and the 1x1 conv (128 -> 64) [+ residual] that consumes it, in ONE launch:
  *   confuse(relu(conv3(.))) / confuse_c(relu(conv6(.))) / torch.add(confuse_fuse(relu(conv10(.))), fuse)
  *   /root/reference/CODON_X4/CODON_x4.py:81-84,125-128.
@@ -289,8 +298,9 @@ int codon_cac_bwd_reduce(int32_t batch, int32_t height, int32_t width, const cod
                          float* part_gch, int32_t* part_arg, int32_t dtype, codon_stream_t stream);
 /* 16-bit tensors: pass A that ALSO writes argch (B,H,W) int32 = the first arg-max channel of every pixel's channel max-pool
  * in Fcat order (255 if none; pooled = the forward's (B,2,H,W) {max, mean} map) and folds dL/d(out) into the running
- * dL/d(inputs): g_in (+)= g_out, g_in_c (+)= g_out_c (accumulate_in = 0: plain copy).  With codon_conv1x1_bwd_gated this
- * replaces codon_cac_bwd_apply in a training step. */
+ * dL/d(inputs): g_in (+)= g_out, g_in_c (+)= g_out_c (accumulate_in = 1: add, 0: plain copy, 2: leave g_in alone -- the
+ * convs that produced g_out already added it, codon_conv2d_sum_into_fwd).  With codon_conv1x1_bwd_gated this replaces
+ * codon_cac_bwd_apply in a training step. */
 int codon_cac_bwd_reduce_acc(int32_t batch, int32_t height, int32_t width, const codon_tensor* g_out,
                              const codon_tensor* g_out_c, const codon_tensor* pre, const codon_tensor* pre_c,
                              const float* ch, const float* sp, const float* pools, const float* pooled, float* g_z,

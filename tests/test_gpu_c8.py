@@ -483,6 +483,47 @@ def test_training_schedules_agree_bit_for_bit():
         A.MASK_IN_EPILOGUE = oldm
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], g4[n]), n
+    # ... and dL/d(inputs) += dL/d(out_i) in the last dgrad's epilogue (codon_conv2d_sum_into_fwd) or in the reduce pass
+    olds = A.SUM_IN_DGRAD
+    try:
+        A.SUM_IN_DGRAD = not olds
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g5 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.SUM_IN_DGRAD = olds
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], g5[n]), n
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 1, 1), (1, 33, 70)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv_sum_into_equals_conv_then_add(shape, dtype, accumulate):
+    """codon_conv2d_sum_into_fwd: y (+)= conv5x5(x) and total += y in ONE epilogue == codon_conv2d_fwd followed by an
+    elementwise add of the STORED y (codon_ew_add_mask), bit for bit, on slices of wider buffers; y also against torch's
+    transposed conv (the launch is a dgrad: PACK_DGRAD weights)."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    q = lambda c, seed: _rand((B, c, H, W), seed).to(dtype).float().to(dev)
+    w = _rand((64, 64, 5, 5), 2, scale=(2.0 / (25 * 64)) ** 0.5).to(dev)
+    wp = ops.packed_weight(w, L.PACK_DGRAD, dtype)
+    gy_f, prev_f, tot_f = q(128, 3), q(128, 5), q(192, 6)
+    gy = ops.from_nchw(gy_f, dtype)
+    y0, y1 = ops.from_nchw(prev_f, dtype), ops.from_nchw(prev_f, dtype)
+    t0, t1 = ops.from_nchw(tot_f, dtype), ops.from_nchw(tot_f, dtype)
+    ops.conv2d(Slice(gy, 64, 64), wp, Slice(y0, 64, 64), 5, accumulate=accumulate)
+    ops.ew_add_mask(Slice(t0, 128, 64), Slice(y0, 64, 64))
+    ops.conv2d_sum_into(Slice(gy, 64, 64), wp, Slice(y1, 64, 64), 5, Slice(t1, 128, 64), accumulate=accumulate)
+    assert torch.equal(y1, y0) and torch.equal(t1, t0)
+    assert torch.equal(ops.to_nchw(t1)[:, :128].float(), tot_f[:, :128])       # the rest of the buffer is untouched
+    ref = F.conv_transpose2d(gy_f[:, 64:], w.to(dtype).float(), padding=2) + (prev_f[:, 64:] if accumulate else 0)
+    assert rel_rmse(ops.to_nchw(y1)[:, 64:].float().cpu(), ref.cpu()) < _tol(dtype)
+    ref_t = tot_f[:, 128:] + ops.to_nchw(y1)[:, 64:].float()
+    assert torch.equal(ops.to_nchw(t1)[:, 128:].float(), ref_t.to(dtype).float())
 
 
 @pytest.mark.parametrize("dtype", DT)
