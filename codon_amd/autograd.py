@@ -182,9 +182,11 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
 
     # ---- MC + CAC blocks 4..0                                                           :74-118
     in2 = S["in2"]
-    g_in2 = new(128)                                # running dL/d[inputs | inputs_c]
     g_pre2 = None if fused_cac else new(128)
     sum_in = fused_cac and SUM_IN_DGRAD             # dL/d(inputs) += dL/d(out_{i-1}) by block i's last dgrads
+    # running dL/d[inputs | inputs_c].  sum_in: its first term IS dL/d(out_4) -- that buffer is kept (no copy) and block 4's
+    # input gradients go to a fresh one
+    g_in2 = g_oc if sum_in else new(128)
     for i in (4, 3, 2, 1, 0):
         Bk = S[f"blk{i}"]
         xin, r2, r2_c, pre2 = Bk["x"], Bk["r2"], Bk["r2_c"], Bk["pre2"]
@@ -199,7 +201,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
                 Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
                 f32(asp.spatial.conv.weight), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
-                accumulate_in=((0 if i == 4 else 2) if sum_in else (i != 4)))
+                accumulate_in=(2 if sum_in else (i != 4)))
         else:
             dw1, db1, dw2, db2, dws = ops.cac_backward(
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
@@ -212,7 +214,8 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         G[f"attention_s{i}.spatial.conv.weight"] = dws
         # block input gradient: blocks 1..4 read oc_{i-1}; block 0 reads in2 (accumulate there)
         if i > 0:
-            g_x, acc0 = g_oc, False                 # g_oc is dead after cac_backward: reuse it
+            # g_oc is dead after this block's cac_backward + 1x1 backward launches: reuse it (unless it just became g_in2)
+            g_x, acc0 = (new(128) if (sum_in and i == 4) else g_oc), False
         else:
             g_x, acc0 = g_in2, True
         # depth stream: pre = confuse(r2); r2 = relu(conv3(stage)); stage = [relu(conv1(x)) | relu(conv2(x))]
@@ -250,6 +253,8 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             ops.conv2d_sum_into(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, Slice(g_in2, 64, 64), accumulate=True)
         else:
             ops.conv2d(Slice(g_stage, 0, 64), Pd("conv4"), Slice(g_x, 64, 64), 5, accumulate=True, **last1)
+        if i > 0:
+            g_oc = g_x                              # dL/d[out | out_c] of block i-1
     del g_oc, g_pre2, g_r2, g_stage
 
     # ---- heads: in2 = [relu(conv_input(stem)) | relu(conv_input_c(stem_c))]            :68-72
