@@ -104,9 +104,9 @@ def alg_bytes(name, P, es, mode):
              # per block: g_out, pre in; g_pre, g_in out (2 x 64 channels each) = 8 x 64; blocks 3..0 also READ the running
              # g_in (accumulate): 10 x 64 -- a training step launches 1 + 4 of them: 9.6 x 64 on average
              "cac_bwd_apply_c8_kernel": 9.6 * 64 * es * P, "cac_bwd_reduce_c8_kernel": 4 * 64 * es * P,
-             # fused pass A: g_out, pre in (4 x 64), g_in out (2 x 64), g_in in on 4 of the 5 launches of a step (1.6 x 64),
-             # + sp, pooled max in, g_z, argch out (4 B per pixel each)
-             "cac_bwd_reduce_acc_c8_kernel": 7.6 * 64 * es * P + 16 * P}
+             # fused pass A: g_out, pre in (4 x 64) + sp, pooled max in, g_z, argch out (4 B per pixel each).  dL/d(inputs) is
+             # no longer touched here (autograd.SUM_IN_DGRAD: the last dgrad convs add it; before: + 3.6 x 64)
+             "cac_bwd_reduce_acc_c8_kernel": 4 * 64 * es * P + 16 * P}
     for k, v in table.items():
         if name.startswith(k):
             return (v, "single role")
