@@ -205,7 +205,11 @@ int codon_conv2d_sum_into_fwd(const codon_conv_desc* d, const void* x, const voi
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: packed weights not 16-byte aligned");
   CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
                 "conv2d_sum_into_fwd: 16-bit dtypes only (dtype %d)", d->dtype);
-  CODON_REQUIRE(sum != y && sum != x, CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: sum aliases x or y");
+  // `sum` may be another channel slice of the buffer that holds y (or x), never an overlapping one
+  auto disjoint = [](int a0, int an, int b0, int bn) { return a0 + an <= b0 || b0 + bn <= a0; };
+  CODON_REQUIRE((sum != y || (d->r_ctotal == d->y_ctotal && disjoint(d->r_coff, d->cout, d->y_coff, d->cout))) &&
+                    (sum != x || (d->r_ctotal == d->x_ctotal && disjoint(d->r_coff, d->cout, d->x_coff, d->cin))),
+                CODON_ERR_BAD_ARG, "conv2d_sum_into_fwd: sum overlaps x or y");
   return conv2d_sum_into_16(d, x, w_packed, y, sum, (hipStream_t)stream);
 }
 

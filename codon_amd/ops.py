@@ -177,8 +177,9 @@ def conv2d_sum_into(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, tota
     B, H, W = _bhw(x.buf)
     assert _bhw(y.buf) == (B, H, W) == _bhw(total.buf) and total.c == y.c and is_c8(x.buf.dtype)
     assert total.buf.dtype == y.buf.dtype == x.buf.dtype
-    # total may live in the same ALLOCATION as nothing else here: it must not overlap y or x
-    assert total.buf.data_ptr() not in (y.buf.data_ptr(), x.buf.data_ptr())
+    for other in (y, x):                  # total may be another channel slice of y's or x's buffer, never an overlapping one
+        assert total.buf.data_ptr() != other.buf.data_ptr() or (
+            total.coff + total.c <= other.coff or other.coff + other.c <= total.coff)
     d = L.ConvDesc(B, H, W, x.c, y.c, ksize, x.ctotal, x.coff, y.ctotal, y.coff, total.ctotal, total.coff,
                    L.CONV_ACCUM_OUT if accumulate else 0, _dt(x.buf))
     prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
