@@ -12,7 +12,7 @@ batch to the oracle.
   C5  x16 fwd  b8   1920x2560 bf16   /root/reference/CODON_X16/CODON_x16.py:136-202
 
 Tolerances: fp32 RMSE <= 1e-4 absolute (north_star); bf16 rel-RMSE <= 3e-2 vs the fp32 oracle (the reference's own
-bf16 CPU run sits at 1.8e-2); gradients: whole vector <= 1e-4 (fp32) / linearity <= 2e-3 (bf16)."""
+bf16 CPU run sits at 1.8e-2); gradients: whole vector <= 1e-4 (fp32) / <= 2e-2 vs the oracle and linearity <= 2e-3 (bf16)."""
 import os
 
 import numpy as np
@@ -177,4 +177,29 @@ def test_c3_shape_fp32_gradient_of_one_image_vs_oracle_autograd():
             den += float(gref[k].double().pow(2).sum())
     assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
     del m, out
+    _free()
+    # ... and the bf16 backward (the dtype of the metric's fwd+bwd half) at the same size against the same oracle
+    # gradient, same upstream gradient -- an oracle comparison at full size, not only a property.  Measured on MI355X:
+    # whole vector 7.6e-3, worst conv tensor (>= 36 864 elements) 1.4e-2 (conv5.weight); at this size the sums run over
+    # 307 200 pixels and the 16-bit rounding noise averages out further than in the 2x24x20 fixtures (where the
+    # reference's own bf16 autograd sits at 1-3e-2 on such tensors, tests/golden/bf16grad_*.npz)
+    mb = _model("x4", sd).set_compute_dtype(torch.bfloat16)
+    mb.train()
+    outb = mb(x.cuda(), y.cuda())
+    assert rel_rmse(outb.detach().float().cpu(), out_ref) <= 3e-2
+    outb.backward(g_up)
+    num = den = 0.0
+    worst = ("", 0.0)
+    for k, p in mb.named_parameters():
+        if k in gref:
+            d2 = float((p.grad.cpu().double() - gref[k].double()).pow(2).sum())
+            r2 = float(gref[k].double().pow(2).sum())
+            num += d2
+            den += r2
+            if p.numel() >= 36864 and (d2 / r2) ** 0.5 > worst[1]:
+                worst = (k, (d2 / r2) ** 0.5)
+    print(f"[1x480x640 bf16 backward vs oracle fp32 autograd] whole vector {(num / den) ** 0.5:.3e}, worst large tensor {worst}")
+    assert (num / den) ** 0.5 <= 2e-2, (num / den) ** 0.5
+    assert worst[1] <= 4e-2, worst
+    del mb, outb
     _free()
