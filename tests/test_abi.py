@@ -97,3 +97,16 @@ def test_no_cpu_fallback_and_no_oracle_in_product():
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "F.conv2d" not in src and "nn.functional.conv2d" not in src, f
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table ("Entry point | Replaces (reference file:line)") covers the whole header: a new entry point
+    without a stated counterpart in the reference fails here."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "codon_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    fns = sorted(set(re.findall(r"\b(codon_[a-z0-9_]+)\s*\(", header)))
+    assert len(fns) >= 45
+    missing = [f for f in fns if f not in doc]
+    assert not missing, missing
