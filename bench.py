@@ -386,9 +386,7 @@ def max_over_ranks(v, dist, ctrl=None):
     """The contract's MAX over ranks of a host-side time: a CPU tensor on the control group."""
     if dist is None:
         return float(v)
-    t = torch.tensor([v], dtype=torch.float64)
-    if ctrl is None and dist.get_backend() == "nccl":
-        t = t.cuda()
+    t = torch.tensor([v], dtype=torch.float64)          # ctrl is a gloo group (or the default group IS gloo): host tensor
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctrl)
     return float(t.item())
 
