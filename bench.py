@@ -391,26 +391,43 @@ def max_over_ranks(v, dist, ctrl=None):
     return float(t.item())
 
 
-def rccl_probe(dist, dev, world, ctrl):
+def rccl_probe(dist, dev, world, ctrl, timeout_s=None):
     """First RCCL collective of the run: one all-reduce of a single element on the default (RCCL) group -- this is where
-    the communicator over xGMI is formed.  Never fatal: the forward has no data-path collective, so when RCCL cannot form
-    a communicator (or returns a wrong sum) the run continues with every collective on the gloo control group and the line
-    says so (`rccl_probe.ok` false, `backend` "gloo").  All ranks take the same decision (MIN over the control group)."""
+    the communicator over xGMI is formed.  Never fatal AND bounded: the forward has no data-path collective, so when RCCL
+    cannot form a communicator, returns a wrong sum, or HANGS (one rank missing, a stuck fabric) the run continues with every
+    collective on the gloo control group and the line says so (`rccl_probe.ok` false, `backend` "gloo").  The collective
+    runs on a helper thread that the caller waits for at most CODON_RCCL_PROBE_TIMEOUT_S (default 90 s): a symmetric
+    exception, an asymmetric one (the other ranks then wait for the missing peer) and a hang all end at the vote below
+    within that time.  All ranks take the same decision (MIN over the control group).  A helper thread still stuck in RCCL
+    is left behind (daemon); main() then leaves through os._exit so that no destructor waits for it."""
+    import threading
+    timeout_s = float(timeout_s if timeout_s is not None else os.environ.get("CODON_RCCL_PROBE_TIMEOUT_S", "90"))
     t0 = time.perf_counter()
-    ok, err, got = False, None, None
-    try:
-        t = torch.ones(1, device=dev)
-        dist.all_reduce(t)
-        torch.cuda.synchronize(dev)
-        got = float(t.item())
-        ok = abs(got - world) < 1e-6
-        if not ok:
-            err = f"all_reduce(1) over {world} ranks returned {got}"
-    except Exception as e:              # noqa: BLE001 -- reported in the line
-        err = f"{type(e).__name__}: {e}"[:600]
-    flag = torch.tensor([1.0 if ok else 0.0])
+    res = {"ok": False, "err": None}
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t)
+            torch.cuda.synchronize(dev)
+            got = float(t.item())
+            res["ok"] = abs(got - world) < 1e-6
+            if not res["ok"]:
+                res["err"] = f"all_reduce(1) over {world} ranks returned {got}"
+        except Exception as e:          # noqa: BLE001 -- reported in the line
+            res["err"] = f"{type(e).__name__}: {e}"[:600]
+
+    th = threading.Thread(target=work, name="rccl_probe", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    hung = th.is_alive()
+    ok, err = (False, f"no answer from RCCL within {timeout_s:.0f} s (communicator setup or the first all-reduce hangs)") if hung \
+        else (res["ok"], res["err"])
+    flag = torch.tensor([1.0 if ok else 0.0, 0.0 if hung else 1.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctrl)
-    return {"ok": bool(flag.item() == 1.0), "this_rank_ok": ok, "error": err, "ms": (time.perf_counter() - t0) * 1e3}
+    return {"ok": bool(flag[0].item() == 1.0), "this_rank_ok": ok, "error": err, "hung": hung,
+            "any_rank_hung": bool(flag[1].item() == 0.0), "ms": (time.perf_counter() - t0) * 1e3, "timeout_s": timeout_s}
 
 
 def software_versions(backend):
@@ -487,6 +504,9 @@ def main():
             # the barriers around the timed region, the max over ranks, the rank records -- runs on a gloo group beside
             # it: the forward shards images and has no data-path collective, so its measurement must not depend on the
             # health of a fabric it does not use.  Training's gradient all-reduce and the self-check go through RCCL.
+            # a collective that times out raises in the waiting thread instead of tearing the process down (the probe's
+            # fallback needs the process alive); the bench still ends non-zero if a gradient all-reduce ever times out
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "2")
             dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=int(os.environ.get("CODON_RCCL_TIMEOUT_S", "600"))))
             ctrl = dist.new_group(backend="gloo")
             probe = rccl_probe(dist, dev, world, ctrl)
@@ -691,6 +711,10 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier(group=ctrl)
+        if probe is not None and probe.get("any_rank_hung"):
+            # a probe thread is still inside RCCL on some rank: no destructor (here or on a peer) may wait for it
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

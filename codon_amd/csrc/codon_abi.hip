@@ -171,6 +171,11 @@ int codon_conv2d_fwd(const codon_conv_desc* d, const void* x, const void* w_pack
                 "conv2d_fwd: input slice [%d,%d) outside %d channels", d->x_coff, d->x_coff + d->cin, d->x_ctotal);
   CODON_REQUIRE(d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal, CODON_ERR_BAD_ARG,
                 "conv2d_fwd: output slice [%d,%d) outside %d channels", d->y_coff, d->y_coff + d->cout, d->y_ctotal);
+  // only the public CODON_CONV_* bits: the kernels keep internal selector bits above them (conv_c8.hip: a read-write running
+  // sum in the residual slot), which no caller of THIS entry point may reach -- `residual` is const here
+  CODON_REQUIRE((d->flags & ~(CODON_CONV_RELU | CODON_CONV_ADD_RESIDUAL | CODON_CONV_ACCUM_OUT | CODON_CONV_MASK_RELU |
+                              CODON_CONV_F16X3 | CODON_CONV_MASK_SUM)) == 0,
+                CODON_ERR_BAD_ARG, "conv2d_fwd: unknown flag bits 0x%x", (unsigned)d->flags);
   CODON_REQUIRE(!((d->flags & CODON_CONV_ADD_RESIDUAL) && (d->flags & CODON_CONV_MASK_RELU)), CODON_ERR_BAD_ARG,
                 "conv2d_fwd: ADD_RESIDUAL and MASK_RELU share the residual slot");
   if (d->flags & (CODON_CONV_ADD_RESIDUAL | CODON_CONV_MASK_RELU)) {

@@ -13,6 +13,10 @@ class GraphedCODON:
     def __init__(self, model, example_x: torch.Tensor, example_y: torch.Tensor, warmup: int = 2):
         if not example_x.is_cuda:
             raise RuntimeError("GraphedCODON needs HIP tensors")
+        if warmup < 1:
+            # the warm-up forward is what packs the weights, allocates the weight guard's pinned flag word and RECORDS the
+            # checksum the captured launch compares with; none of that may happen for the first time under capture
+            raise ValueError("GraphedCODON: warmup must be >= 1")
         self.model = model.eval()
         self.x = example_x.detach().clone().float().contiguous()
         self.y = example_y.detach().clone().float().contiguous()

@@ -48,8 +48,22 @@ def _half_chip_streams(dev, main_stream):
     i = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (i, main_stream.cuda_stream, threading.get_ident())
     if key not in _HALF_STREAMS:
+        _prune_dead_threads(_HALF_STREAMS, 2)
         _HALF_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
     return _HALF_STREAMS[key]
+
+
+def _prune_dead_threads(table: dict, tid_index: int, keep: int = 16):
+    """Per-(thread, stream) tables -- the side streams above, _WeightGuard.states -- would grow by one entry per short-lived
+    caller thread (thread pools, nn.DataParallel's per-forward threads): before a new entry goes in, entries of threads that
+    no longer exist are dropped once the table holds more than `keep`.  Their device memory returns to the caching
+    allocator, which orders its reuse behind the work already enqueued on the stream it was used on."""
+    if len(table) < keep:
+        return
+    import threading
+    alive = {t.ident for t in threading.enumerate()}
+    for k in [k for k in table if k[tid_index] not in alive]:
+        del table[k]
 
 
 # debug: re-pack on every cache hit and compare, so a write through `.data` after the first forward (the reference's own
@@ -119,6 +133,7 @@ class _WeightGuard:
         st = self.states.get(key)
         lib = L.load()
         if st is None or st[1].device != dev:
+            _prune_dead_threads(self.states, 0)
             n = lib.codon_weight_checksum_workspace_bytes() // 8 + 1          # + the reference slot (last word)
             st = self.states[key] = [None, torch.zeros(n, dtype=torch.int64, device=dev), None, None]
         mode = 1
@@ -134,6 +149,11 @@ class _WeightGuard:
             donor = None
             if torch.cuda.is_current_stream_capturing():
                 donor = next((o for o in self.states.values() if o is not st and o[0] == tag and o[1].device == dev), None)
+                if donor is None:
+                    del self.states[key]
+                    raise RuntimeError("codon_amd: hipGraph capture of a forward whose weights no eager forward has seen "
+                                       "yet -- the captured weight-checksum launch would RECORD on every replay and never "
+                                       "compare; run one forward outside the capture first (GraphedCODON does: warmup >= 1)")
             st[0], st[2] = tag, d
             st[3], mode = (donor[3], 1) if donor is not None else (st[1], 0)
         ref = st[3]
@@ -166,13 +186,46 @@ class Conv2dParams(nn.Module):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, bias=False"
 
 
-class BasicConv(nn.Module):  # CAC_module.py:6-20 (bn=False, relu=False on this path)
-    def __init__(self, in_planes, out_planes, kernel_size):
+_POOLS_BUILT = ("avg", "max")
+
+
+def _refuse(what: str):
+    raise NotImplementedError(f"codon_amd: {what} -- the HIP kernels implement the configuration CODONNet itself uses "
+                              "(CODON_x4.py:54-65) and nothing else; there is no eager fallback")
+
+
+def _check_pool_types(cls: str, pool_types):
+    """The reference branches on pool_types in {'avg','max','lp','lse'} (CAC_module.py:41-56, attention/ResCBAM.py:40-55);
+    the kernels compute the global average AND max pool, each exactly once (their order does not matter: the two MLP
+    outputs are added, and a two-term fp32 sum commutes bit for bit)."""
+    pt = list(pool_types)
+    if sorted(pt) != sorted(_POOLS_BUILT):
+        _refuse(f"{cls}(pool_types={pt!r}): only ['avg', 'max'] is built")
+
+
+class BasicConv(nn.Module):
+    """CAC_module.py:6-20 / attention/ResCBAM.py:6-20, with the reference's signature AND defaults (relu=True, padding=0).
+    The one configuration the kernels implement is the spatial gate's BasicConv(2, 1, 5, stride=1, padding=2, relu=False)
+    (CAC_module.py:88): everything else is refused at construction instead of silently computing something different."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, dilation=1, groups=1, relu=True, bn=False,
+                 bias=False):
         super().__init__()
+        cfg = dict(in_planes=in_planes, out_planes=out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
+                   dilation=dilation, groups=groups, relu=relu, bn=bn, bias=bias)
+        built = dict(in_planes=2, out_planes=1, kernel_size=5, stride=1, padding=2, dilation=1, groups=1, relu=False,
+                     bn=False, bias=False)
+        bad = {k: v for k, v in cfg.items() if v != built[k] and (v, built[k]) not in (((5, 5), 5), ((2, 2), 2), ((1, 1), 1))}
+        if bad:
+            _refuse("BasicConv(" + ", ".join(f"{k}={v!r}" for k, v in bad.items()) + "): only BasicConv(2, 1, 5, stride=1, "
+                    "padding=2, relu=False) (the 5x5 2->1 conv of CAC_spatial, no BatchNorm, no ReLU, no bias) is built")
         self.out_channels = out_planes
-        self.conv = Conv2dParams(in_planes, out_planes, kernel_size)
+        self.conv = Conv2dParams(in_planes, out_planes, 5)
         self.bn = None
         self.relu = None
+
+    def forward(self, x):
+        _refuse("BasicConv.forward: parameter holder; the conv runs inside CODONNet.forward (cac_spatial_kernel)")
 
 
 class Flatten(nn.Module):  # CAC_module.py:22-24 (index 0 of the mlp Sequential; no parameters)
@@ -180,33 +233,87 @@ class Flatten(nn.Module):  # CAC_module.py:22-24 (index 0 of the mlp Sequential;
         return x.view(x.size(0), -1)
 
 
-class CAC_channel(nn.Module):  # CAC_module.py:26-36
+class CAC_channel(nn.Module):
+    """CAC_module.py:26-36.  Built: gate_channels=128, reduction_ratio=16 (the 128 -> 8 -> 64 MLP of cac_gate_kernel),
+    pool_types = avg + max.  Other arguments are refused at construction (and again at the first forward, for modules that
+    arrive by pickle or have their attributes edited)."""
+
     def __init__(self, gate_channels, reduction_ratio=16, pool_types=("avg", "max")):
         super().__init__()
+        if gate_channels != 128 or reduction_ratio != 16:
+            _refuse(f"CAC_channel(gate_channels={gate_channels}, reduction_ratio={reduction_ratio}): only (128, 16) is built")
+        _check_pool_types("CAC_channel", pool_types)
         self.gate_channels = gate_channels
         self.mlp = nn.Sequential(Flatten(), nn.Linear(gate_channels, gate_channels // reduction_ratio), nn.ReLU(),
                                  nn.Linear(gate_channels // reduction_ratio, gate_channels // 2))
         self.pool_types = list(pool_types)
 
+    def forward(self, x):
+        _refuse("CAC_channel.forward: parameter holder; the gate runs inside CODONNet.forward (cac_gate_kernel)")
 
-class ChannelGate(nn.Module):  # attention/ResCBAM.py:26-37 -- state only (attention_c5)
+
+class ChannelGate(nn.Module):
+    """attention/ResCBAM.py:26-37 -- state only in CODONNet (attention_c5, CODON_x4.py:64: registered, never called);
+    executed by BaseNet_RMCR_fuseRMCR_cross only, as ChannelGate(64): (64, 16, avg + max) is what is built."""
+
     def __init__(self, gate_channels, reduction_ratio=16, pool_types=("avg", "max")):
         super().__init__()
+        if gate_channels != 64 or reduction_ratio != 16:
+            _refuse(f"ChannelGate(gate_channels={gate_channels}, reduction_ratio={reduction_ratio}): only (64, 16) is built")
+        _check_pool_types("ChannelGate", pool_types)
         self.gate_channels = gate_channels
         self.mlp = nn.Sequential(Flatten(), nn.Linear(gate_channels, gate_channels // reduction_ratio), nn.ReLU(),
                                  nn.Linear(gate_channels // reduction_ratio, gate_channels))
         self.pool_types = list(pool_types)
 
+    def forward(self, x):
+        _refuse("ChannelGate.forward: parameter holder (never called on the CODONNet path, CODON_x4.py:64)")
+
 
 class ChannelPool(nn.Module):  # CAC_module.py:78-81 (no parameters; fused into cac_stats)
-    pass
+    def forward(self, x):
+        _refuse("ChannelPool.forward: no parameters, fused into the statistics kernels of CODONNet.forward")
 
 
 class CAC_spatial(nn.Module):  # CAC_module.py:83-89
     def __init__(self):
         super().__init__()
         self.compress = ChannelPool()
-        self.spatial = BasicConv(2, 1, 5)
+        self.spatial = BasicConv(2, 1, 5, stride=1, padding=2, relu=False)
+
+    def forward(self, x):
+        _refuse("CAC_spatial.forward: parameter holder; the gate runs inside CODONNet.forward (cac_spatial_kernel)")
+
+
+def _check_gates(model, n_gates: int = 5, gate5: bool = False):
+    """First-forward audit of the gate modules as they ARE (a whole-module pickle of the reference bypasses the
+    constructors above, and attributes can be edited): what the kernels do not implement raises here."""
+    for i in range(n_gates):
+        ac, asp = getattr(model, f"attention_c{i}"), getattr(model, f"attention_s{i}")
+        _check_pool_types(f"attention_c{i}", ac.pool_types)
+        if tuple(ac.mlp[1].weight.shape) != (8, 128) or tuple(ac.mlp[3].weight.shape) != (64, 8):
+            _refuse(f"attention_c{i}: MLP {tuple(ac.mlp[1].weight.shape)} -> {tuple(ac.mlp[3].weight.shape)}; only 128 -> 8 -> 64 is built")
+        _check_spatial(f"attention_s{i}", asp)
+    if gate5:
+        g5 = model.attention_c5
+        _check_pool_types("attention_c5", g5.pool_types)
+        if tuple(g5.mlp[1].weight.shape) != (4, 64) or tuple(g5.mlp[3].weight.shape) != (64, 4):
+            _refuse(f"attention_c5: MLP {tuple(g5.mlp[1].weight.shape)} -> {tuple(g5.mlp[3].weight.shape)}; only 64 -> 4 -> 64 is built")
+        _check_spatial("attention_s5", model.attention_s5)
+
+
+def _check_spatial(name: str, asp):
+    sc = asp.spatial
+    if getattr(sc, "bn", None) is not None or getattr(sc, "relu", None) is not None:
+        _refuse(f"{name}.spatial with BatchNorm / ReLU (BasicConv(bn=True / relu=True)): only the bare conv is built")
+    conv = sc.conv
+    if getattr(conv, "bias", None) is not None or tuple(conv.weight.shape) != (1, 2, 5, 5):
+        _refuse(f"{name}.spatial.conv: weight {tuple(conv.weight.shape)}, bias {getattr(conv, 'bias', None) is not None}; "
+                "only the bias-free 5x5 2->1 conv is built")
+    for attr, want in (("stride", (1, 1)), ("padding", (2, 2)), ("dilation", (1, 1)), ("groups", 1)):
+        have = getattr(conv, attr, want)
+        if have != want:
+            _refuse(f"{name}.spatial.conv.{attr} = {have!r}; only {want!r} is built")
 
 
 _MAIN_CONVS = [  # (name, cin, cout, k) in the reference's registration order, CODON_x4.py:24-47
@@ -241,6 +348,13 @@ class _CODONBase(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None
         self.conv_precision: str = "exact"
         self.recompute: bool = False
+
+    def check_supported(self):
+        """Raise NotImplementedError if a gate sub-module is configured for something the kernels do not implement
+        (pool_types other than avg + max, BatchNorm / ReLU / bias in the spatial conv, other MLP shapes): run by every
+        forward on the modules as they are -- a whole-module pickle of the reference bypasses the constructors."""
+        _check_gates(self, gate5=isinstance(self, BaseNet_RMCR_fuseRMCR_cross))
+        return self
 
     def set_recompute(self, on: bool = True):
         """Training memory switch: do not keep the 13 `stage` tensors (cat(relu(conv1), relu(conv2)) and siblings,
@@ -322,17 +436,21 @@ class _CODONBase(nn.Module):
         if g is None:
             return self
         if synchronize and torch.cuda.is_available():
-            torch.cuda.synchronize()
+            # every device a checksum launch went to (the module may live on another device than the current one)
+            for d in {st[1].device for st in g.states.values()} or {torch.device("cuda", torch.cuda.current_device())}:
+                torch.cuda.synchronize(d)
         if g.tripped():
             raise RuntimeError(_STALE_MSG)
         return self
 
     def _apply(self, fn, *a, **k):
-        self._pack_cache.clear()
+        # weights legitimately replaced: the cache AND a tripped guard go (a stale forward before this point has been
+        # reported or is moot -- the weights it disagreed with no longer exist)
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._pack_cache.clear()
+        self.invalidate_packed()
         return super()._load_from_state_dict(*a, **k)
 
     def _split(self, ksize: int) -> bool:
@@ -406,6 +524,7 @@ class _CODONBase(nn.Module):
         backward needs is kept in fresh buffers; without it buffers are reused across blocks."""
         B, _, H, W = x.shape
         dev = x.device
+        self.check_supported()
         self._guard(dev)
         adt = self._act_dtype()
         new = lambda c: ops.new_act(B, c, H, W, adt, dev)
@@ -630,11 +749,11 @@ class BaseNet_RMCR_fuseRMCR(nn.Module):
     invalidate_packed = _CODONBase.invalidate_packed
 
     def _apply(self, fn, *a, **k):
-        self._pack_cache.clear()
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._pack_cache.clear()
+        self.invalidate_packed()
         return super()._load_from_state_dict(*a, **k)
 
     def forward(self, x, y):
@@ -710,6 +829,7 @@ class BaseNet_RMCR_fuseRMCR_cross(_CODONBase):
         x, y = x.float().contiguous(), y.float().contiguous()
         B, _, H, W = x.shape
         dev = x.device
+        self.check_supported()
         self._guard(dev)
         adt = self._act_dtype()
         new = lambda c: ops.new_act(B, c, H, W, adt, dev)
