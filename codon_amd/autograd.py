@@ -36,6 +36,16 @@ FUSED_CAC_BWD = _os.environ.get("CODON_FUSED_CAC_BWD", "1") != "0"
 # both streams: matrix-bound, the extra 2.5 GB ride along) instead of in the HBM-bound reduce pass (ops.conv2d_sum_into);
 # 0 = in the reduce pass (A/B).  Bit-identical either way.
 SUM_IN_DGRAD = _os.environ.get("CODON_SUM_IN_DGRAD", "1") != "0"
+# 16-bit: dL/d(fuse) = (dL/df_3 + dL/df_2 + dL/df_1 + dL/df_0) * [fuse > 0] collected by the trunk's own input-gradient convs:
+# dL/df_3's buffer is the running sum, the conv5x5 that completes dL/df_2 / dL/df_1 adds it there (ops.conv2d_sum_into), the
+# two convs of iteration 0 accumulate straight into it and the last one applies the mask (CODON_CONV_MASK_SUM) -- no pass over
+# the four tensors.  0 = ops.ew_sum_mask (A/B).  fuse = relu(conv7(..)), f_{i+1} = confuse_fuse(..) + fuse: CODON_x4.py:119-128
+SUM_GFUSE_IN_DGRAD = _os.environ.get("CODON_SUM_GFUSE_IN_DGRAD", "1") != "0"
+
+# every fixed-order reduction of the backward (56 weight-gradient reduces, 30 CAC parameter sums, 3 one-channel reduces) as
+# ONE launch at the end (ops.DeferredReduce / codon_reduce_multi), bit-identical results; 0 = a small launch behind each
+# producer (A/B)
+DEFER_REDUCE = _os.environ.get("CODON_DEFER_REDUCE", "1") != "0"
 
 # parameters in a fixed order: the flat gradient buffer of codon_amd.dist uses the same order
 _CONVS = ["input", "conv_input", "conv1", "conv2", "conv3", "confuse", "input_c", "conv_input_c", "conv4", "conv5",
@@ -70,11 +80,32 @@ class _CodonFn(torch.autograd.Function):
         model, S, x, y = ctx.model, ctx.saved, ctx.x, ctx.y
         with torch.no_grad():
             need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-            grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous(), input_grads=need)
+            sink = _grad_sink(model) if all(ctx.needs_input_grad[3:]) else None
+            grads = _backward_impl(model, S, x.contiguous(), y.contiguous(), g_out.contiguous(), input_grads=need, sink=sink)
         ctx.saved = None
         gx = grads["__input"].to(ctx.in_dtype) if need[0] else None
         gyy = grads["__input_c"].to(ctx.in_dtype) if need[1] else None
+        if sink is not None:       # the gradients were ADDED into the parameters' .grad storage by the kernels themselves
+            return (None, gx, gyy) + (None,) * len(sink)
         return (None, gx, gyy) + tuple(grads[n].to(p.dtype) for n, p in used_parameters(model))
+
+
+def _grad_sink(model):
+    """name -> the parameter's .grad tensor, when a codon_amd.dist.GradSync(direct=True) owns the gradients of this model:
+    every used parameter's .grad is then an fp32 view of ONE flat buffer, and the backward kernels ADD into those views
+    directly (what autograd's AccumulateGrad would do with returned tensors, minus 44 add launches and their traffic).
+    None (the ordinary route: gradients are returned to autograd) unless every view is in place."""
+    gs = model.__dict__.get("_grad_sink")
+    gs = gs() if gs is not None else None
+    if gs is None or not gs.direct:
+        return None
+    sink = {}
+    for (n, p), view_ptr in zip(gs.named, gs.view_ptrs):
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or g.data_ptr() != view_ptr or not g.is_contiguous() or g.device != p.device:
+            return None
+        sink[n] = g
+    return sink
 
 
 def codon_apply(model, x, y):
@@ -82,14 +113,27 @@ def codon_apply(model, x, y):
     return _CodonFn.apply(model, x, y, *params)
 
 
-def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
+def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), sink=None):
+    """sink: None = the 44 parameter gradients come back as fresh fp32 tensors (one flat allocation); a dict name -> fp32
+    tensor = they are ADDED into those tensors (codon_amd.dist.GradSync's views of its flat all-reduce buffer)."""
     B, _, H, W = x.shape
     dev = x.device
     adt = model._act_dtype()                       # activation-gradient dtype follows the activations
     new = lambda c: ops.new_act(B, c, H, W, adt, dev)
     f32 = lambda t: t if t.dtype == torch.float32 else t.float()
     gy = f32(gy)
-    G = {}                                         # parameter gradients: always fp32
+    named = used_parameters(model)
+    if sink is not None:
+        G = dict(sink)                             # parameter gradients: always fp32
+    else:
+        flat = torch.empty(sum(p.numel() for _, p in named), dtype=torch.float32, device=dev)
+        G, off = {}, 0
+        for n, p in named:
+            G[n] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+    acc0 = sink is not None                        # the first contribution to a gradient adds (sink) or overwrites
+    red = ops.DeferredReduce() if DEFER_REDUCE else None
+    started = set()                                # immediate form: gradients that hold their first contribution
 
     def Pd(name):
         return model._packed(name, L.PACK_DGRAD)
@@ -121,28 +165,29 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             ops.conv2d(gs, Pd(name), gxs, 1, relu_mask=xs)
             return
         key = name + ".weight"
-        first = key not in G
-        if first:
-            G[key] = torch.empty_like(getattr(model, name).weight, dtype=torch.float32)
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0 or key in started)
+        started.add(key)
         if gate is not None:
-            ops.conv1x1_bwd_gated(xs, gs, Pd(name), gxs, G[key], gate, fcat_base, accumulate=not first)
+            ops.conv1x1_bwd_gated(xs, gs, Pd(name), gxs, G[key], gate, fcat_base, **kw)
         else:
-            ops.conv1x1_bwd(xs, gs, Pd(name), gxs, G[key], accumulate=not first)
+            ops.conv1x1_bwd(xs, gs, Pd(name), gxs, G[key], **kw)
 
     def wgrad(name, xs: Slice, gs: Slice, k: int):
         key = name + ".weight"
-        if key in G:
-            ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=True)
-        else:
-            G[key] = torch.empty_like(getattr(model, name).weight, dtype=torch.float32)
-            ops.conv2d_wgrad(xs, gs, G[key], k, accumulate=False)
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0 or key in started)
+        started.add(key)
+        ops.conv2d_wgrad(xs, gs, G[key], k, **kw)
+
+    def wgrad1ch(name, a: Slice, img, flip: bool):
+        key = name + ".weight"
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0)
+        ops.conv1ch_wgrad(a, img, G[key], flip=flip, **kw)
 
     # ---- tail: y_hat = output(t11) + x ; t11 = relu(conv11(f3))                       :129-131
     t11, f_last = S["t11"], S["f_last"]
     g_t = new(64)
     ops.stencil_1to64(gy, f32(model.output.weight), Slice(g_t), flip=True, mask=Slice(t11))
-    G["output.weight"] = torch.empty_like(model.output.weight, dtype=torch.float32)
-    ops.conv1ch_wgrad(Slice(t11), gy, G["output.weight"], flip=True)
+    wgrad1ch("output", Slice(t11), gy, True)
     wgrad("conv11", Slice(f_last), Slice(g_t), 3)
     g_f = new(64)                                   # dL/df_3 (no ReLU on f)
     ops.conv2d(Slice(g_t), Pd("conv11"), Slice(g_f), 3)
@@ -151,6 +196,8 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
     # ---- fusion trunk, iterations 2..0                                                  :122-128
     g_fs = [g_f]                                    # dL/df_3, dL/df_2, ...: f_{i+1} = confuse_fuse(..) + fuse feeds each into dL/dfuse
     g_r2, g_stage = new(128), new(128)
+    sum_fuse = ops.is_c8(adt) and SUM_GFUSE_IN_DGRAD
+    g_total = g_f                                   # sum_fuse: the running dL/d(fuse); its first term IS dL/df_3 (no copy)
     for i in (2, 1, 0):
         T = S[f"trunk{i}"]
         xin, r2 = T["x"], T["r2"]
@@ -160,13 +207,26 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.conv2d(Slice(g_r2), Pd("conv10"), Slice(g_stage), 5, relu_mask=Slice(stage))
         wgrad("conv8", Slice(xin), Slice(g_stage, 0, 64), 5)
         wgrad("conv9", Slice(xin), Slice(g_stage, 64, 64), 3)
+        if sum_fuse and i == 0:
+            # dL/df_0 is needed nowhere but in the sum (f_0 is fuse itself): both convs accumulate into the running sum, the
+            # last one masks it
+            ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_total), 3, accumulate=True)
+            ops.conv2d(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_total), 5, accumulate=True, relu_mask=Slice(S["fuse"]),
+                       mask_sum=True)
+            break
         g_prev = new(64)
-        ops.conv2d(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_prev), 5)
-        ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_prev), 3, accumulate=True)
+        if sum_fuse:      # the conv3x3 first: the conv5x5 (matrix-bound, HBM to spare) completes dL/df_i and adds it to the sum
+            ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_prev), 3)
+            ops.conv2d_sum_into(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_prev), 5, Slice(g_total), accumulate=True)
+        else:
+            ops.conv2d(Slice(g_stage, 0, 64), Pd("conv8"), Slice(g_prev), 5)
+            ops.conv2d(Slice(g_stage, 64, 64), Pd("conv9"), Slice(g_prev), 3, accumulate=True)
         g_f = g_prev
         g_fs.append(g_f)
     # f_0 is fuse itself: dL/dfuse = (dL/df_3 + dL/df_2 + dL/df_1 + dL/df_0) * [fuse > 0]; fuse = relu(conv7(oc4))   :119-128
-    if SUM_GFUSE:
+    if sum_fuse:
+        g_fuse = g_total
+    elif SUM_GFUSE:
         g_fuse = new(64)
         ops.ew_sum_mask(Slice(g_fuse), [Slice(t) for t in g_fs], mask=Slice(S["fuse"]))
     else:
@@ -174,7 +234,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[1]))
         ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[2]))
         ops.ew_add_mask(Slice(g_fuse), Slice(g_fs[3]), mask=Slice(S["fuse"]))
-    del g_f, g_fs
+    del g_f, g_fs, g_total
     wgrad("conv7", Slice(S["oc"]), Slice(g_fuse), 3)
     g_oc = new(128)                                 # dL/d[out | out_c] of block 4
     ops.conv2d(Slice(g_fuse), Pd("conv7"), Slice(g_oc), 3)
@@ -194,6 +254,9 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
         if debug is not None:
             debug[f"g_oc{i}"] = g_oc.clone()
         gate = None
+        ckeys = (f"attention_c{i}.mlp.1.weight", f"attention_c{i}.mlp.1.bias", f"attention_c{i}.mlp.3.weight",
+                 f"attention_c{i}.mlp.3.bias", f"attention_s{i}.spatial.conv.weight")
+        cdefer = dict(defer=(red, ckeys)) if red is not None else {}
         if fused_cac:
             # no apply pass, no g_pre2: the two 1x1 backward launches below read g_oc itself (depth half first; the depth
             # chain overwrites only channels 0..63 of g_oc / g_x before the colour chain reads 64..127)
@@ -201,17 +264,17 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
                 Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
                 f32(asp.spatial.conv.weight), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
-                accumulate_in=(2 if sum_in else (i != 4)))
+                accumulate_in=(2 if sum_in else (i != 4)), **cdefer)
         else:
             dw1, db1, dw2, db2, dws = ops.cac_backward(
                 Slice(g_oc, 0, 64), Slice(g_oc, 64, 64), Slice(pre2, 0, 64), Slice(pre2, 64, 64), Bk["ch"], Bk["sp"],
                 Bk["pooled"], Bk["pools"], f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
                 f32(asp.spatial.conv.weight),
                 Slice(g_pre2, 0, 64), Slice(g_pre2, 64, 64), Slice(g_in2, 0, 64), Slice(g_in2, 64, 64),
-                accumulate_in=(i != 4))
-        G[f"attention_c{i}.mlp.1.weight"], G[f"attention_c{i}.mlp.1.bias"] = dw1, db1
-        G[f"attention_c{i}.mlp.3.weight"], G[f"attention_c{i}.mlp.3.bias"] = dw2, db2
-        G[f"attention_s{i}.spatial.conv.weight"] = dws
+                accumulate_in=(i != 4), **cdefer)
+        if red is None:             # immediate form (A/B): the five small results go to their places by five small copies / adds
+            for key, t_ in zip(ckeys, (dw1, db1, dw2, db2, dws)):
+                G[key].add_(t_.view_as(G[key])) if acc0 else G[key].copy_(t_.view_as(G[key]))
         # block input gradient: blocks 1..4 read oc_{i-1}; block 0 reads in2 (accumulate there)
         if i > 0:
             # g_oc is dead after this block's cac_backward + 1x1 backward launches: reuse it (unless it just became g_in2)
@@ -265,8 +328,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
                                        ("input_c", "conv_input_c", S["stem_c"], y, 64)):
         wgrad(nm_ci, Slice(st), Slice(g_in2, off, 64), 3)
         ops.conv2d(Slice(g_in2, off, 64), Pd(nm_ci), Slice(g_s), 3, relu_mask=Slice(st))
-        G[nm_in + ".weight"] = torch.empty_like(getattr(model, nm_in).weight, dtype=torch.float32)
-        ops.conv1ch_wgrad(Slice(g_s), img, G[nm_in + ".weight"], flip=False)
+        wgrad1ch(nm_in, Slice(g_s), img, False)
         # dL/d(input image) when asked for: the 64 -> 1 dgrad of the stem is the head stencil with the flipped,
         # transposed kernel; x also feeds the final residual add (CODON_x4.py:67,131): + gy
         if input_grads[off // 64]:
@@ -274,4 +336,6 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False)):
             g_img = torch.empty_like(gy)
             ops.head(Slice(g_s), wt, gy if off == 0 else torch.zeros_like(gy), g_img)
             G["__input_c" if off else "__input"] = g_img
+    if red is not None:
+        red.run(G, accumulate=acc0)
     return G

@@ -432,7 +432,7 @@ int cac_bwd_gate(int B, int H, int W, const float* part_gch, const int* part_arg
   hipLaunchKernelGGL(cac_bwd_gate_kernel, dim3(B), dim3(128), 0, stream, part_gch, part_arg, ch, pools, w1, b1, w2,
                      g_pools, argpix, part_param, nt);
   int st = check_launch("cac_bwd_gate_kernel");
-  if (st != CODON_OK) return st;
+  if (st != CODON_OK || !dw1) return st;       // dw1 == null: the rows stay in part_param for codon_reduce_multi
   // the four gradients are contiguous slices of the per-image partial rows; sum over images, fixed order
   struct { float* out; int off, n; } parts[4] = {{dw1, 0, 1024}, {db1, 1024, 8}, {dw2, 1032, 512}, {db2, 1544, 64}};
   for (auto& q : parts) {
@@ -450,15 +450,18 @@ int cac_bwd_spatial(int B, int H, int W, const float* g_z, const float* pooled, 
   hipLaunchKernelGGL(cac_bwd_spatial_kernel, dim3(nblk), dim3(256), 0, stream, g_z, pooled, w, g_pooled, part_w, H, W,
                      (W + SPB_T - 1) / SPB_T, (H + SPB_T - 1) / SPB_T);
   int st = check_launch("cac_bwd_spatial_kernel");
-  if (st != CODON_OK) return st;
-  // two-level fixed-order sum of the (nblk, 50) partials: 64 chunks in place, then the 64 chunk sums
+  if (st != CODON_OK || !dw) return st;        // dw == null: the rows stay in part_w for codon_reduce_multi
+  // two-level fixed-order sum of the (nblk, 50) partials: 64 chunks in place, then the chunk sums
   const int nchunk = nblk < 64 ? 1 : 64;
   const int per = (nblk + nchunk - 1) / nchunk;
   if (nchunk > 1) {
     hipLaunchKernelGGL(partial_chunk_sum_kernel, dim3(nchunk), dim3(64), 0, stream, part_w, 50, nblk, per);
     st = check_launch("partial_chunk_sum_kernel");
     if (st != CODON_OK) return st;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nchunk, 50L * per, 0);
+    // only the chunks that HOLD rows: with nblk not a multiple of 64 the last chunks start past the last row (round 5: the
+    // second stage used to walk all 64 and read past part_w -- e.g. 300 blocks for one 480 x 640 image: per 5, 60 chunks)
+    const int used = (nblk + per - 1) / per;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, used, 50L * per, 0);
   } else {
     hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, part_w, dw, 50, nblk, 50L, 0);
   }

@@ -103,6 +103,7 @@ int ssim_fwd(int, int, int, const float*, const float*, float*, float*, double*,
 int l1_fwd(long, const float*, const float*, float*, int, double*, hipStream_t);
 int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*, float*, float, float, hipStream_t);
 
+int reduce_multi(const codon_reduce_item*, int, hipStream_t);
 size_t weight_checksum_workspace_bytes();
 int weight_checksum(const codon_wsum_desc*, void*, unsigned long long*, int, int*, hipStream_t);
 
@@ -328,7 +329,8 @@ size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d) {
 
 int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, float* dw, void* workspace,
                        size_t workspace_bytes, int32_t accumulate, codon_stream_t stream) {
-  CODON_REQUIRE(d && x && gy && dw && workspace, CODON_ERR_BAD_ARG, "conv2d_wgrad: null pointer");
+  CODON_REQUIRE(d && x && gy && (dw || accumulate == CODON_WGRAD_DEFER) && workspace, CODON_ERR_BAD_ARG, "conv2d_wgrad: null pointer");
+  CODON_REQUIRE(accumulate >= 0 && accumulate <= CODON_WGRAD_DEFER, CODON_ERR_BAD_ARG, "conv2d_wgrad: accumulate %d", accumulate);
   CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv2d_wgrad: bad shape");
   CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
                     d->y_coff + d->cout <= d->y_ctotal,
@@ -343,8 +345,9 @@ int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, 
 int codon_conv1x1_bwd(const codon_conv_desc* d, const void* x, const void* gy, const void* w_packed_dgrad,
                       const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
                       codon_stream_t stream) {
-  CODON_REQUIRE(d && x && gy && w_packed_dgrad && gx && gx->data && dw && workspace, CODON_ERR_BAD_ARG,
-                "conv1x1_bwd: null pointer");
+  CODON_REQUIRE(d && x && gy && w_packed_dgrad && gx && gx->data && (dw || accumulate == CODON_WGRAD_DEFER) && workspace,
+                CODON_ERR_BAD_ARG, "conv1x1_bwd: null pointer");
+  CODON_REQUIRE(accumulate >= 0 && accumulate <= CODON_WGRAD_DEFER, CODON_ERR_BAD_ARG, "conv1x1_bwd: accumulate %d", accumulate);
   CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv1x1_bwd: bad shape");
   CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
                     d->y_coff + d->cout <= d->y_ctotal && gx->coff >= 0 && gx->coff + d->cin <= gx->ctotal,
@@ -360,9 +363,10 @@ int codon_conv1x1_bwd_gated(const codon_conv_desc* d, const void* x, const void*
                             const codon_tensor* gx, float* dw, void* workspace, size_t workspace_bytes, int32_t accumulate,
                             const float* ch, const float* sp, const float* g_pooled, const float* g_pools,
                             const int32_t* argpix, const int32_t* argch, int32_t fcat_base, codon_stream_t stream) {
-  CODON_REQUIRE(d && x && g_out && w_packed_dgrad && gx && gx->data && dw && workspace && ch && sp && g_pooled && g_pools &&
-                    argpix && argch,
+  CODON_REQUIRE(d && x && g_out && w_packed_dgrad && gx && gx->data && (dw || accumulate == CODON_WGRAD_DEFER) && workspace &&
+                    ch && sp && g_pooled && g_pools && argpix && argch,
                 CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: null pointer");
+  CODON_REQUIRE(accumulate >= 0 && accumulate <= CODON_WGRAD_DEFER, CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: accumulate %d", accumulate);
   CODON_REQUIRE(shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv1x1_bwd_gated: bad shape");
   CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && d->y_coff >= 0 &&
                     d->y_coff + d->cout <= d->y_ctotal && gx->coff >= 0 && gx->coff + d->cin <= gx->ctotal,
@@ -478,10 +482,17 @@ int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codo
                         float* dw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t dtype,
                         codon_stream_t stream) {
   CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "conv1ch_wgrad: dtype %d", dtype);
-  CODON_REQUIRE(slice_ok(a) && s && dw && workspace, CODON_ERR_BAD_ARG, "conv1ch_wgrad: null pointer or bad slice");
+  CODON_REQUIRE(slice_ok(a) && s && (dw || (flip & CODON_W1_DEFER)) && workspace, CODON_ERR_BAD_ARG,
+                "conv1ch_wgrad: null pointer or bad slice");
+  CODON_REQUIRE((flip & ~(CODON_W1_FLIP | CODON_W1_ACCUMULATE | CODON_W1_DEFER)) == 0, CODON_ERR_BAD_ARG, "conv1ch_wgrad: flip 0x%x", (unsigned)flip);
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "conv1ch_wgrad: bad shape");
   return conv1ch_wgrad(batch, height, width, a->data, a->ctotal, a->coff, s, dw, flip, (float*)workspace,
                        workspace_bytes, dtype, (hipStream_t)stream);
+}
+
+int codon_reduce_multi(const codon_reduce_item* items, int32_t n_items, codon_stream_t stream) {
+  CODON_REQUIRE(items && n_items >= 1, CODON_ERR_BAD_ARG, "reduce_multi: no items");
+  return reduce_multi(items, n_items, (hipStream_t)stream);
 }
 
 int codon_ew_add_mask(int32_t batch, int32_t height, int32_t width, int32_t channels, const codon_tensor* dst,
@@ -548,9 +559,9 @@ int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float
                        const float* ch, const float* pools, const float* w1, const float* b1, const float* w2,
                        float* g_pools, int32_t* argpix, float* part_param, float* dw1, float* db1, float* dw2,
                        float* db2, codon_stream_t stream) {
-  CODON_REQUIRE(part_gch && part_arg && ch && pools && w1 && b1 && w2 && g_pools && argpix && part_param && dw1 &&
-                    db1 && dw2 && db2,
-                CODON_ERR_BAD_ARG, "cac_bwd_gate: null pointer");
+  CODON_REQUIRE(part_gch && part_arg && ch && pools && w1 && b1 && w2 && g_pools && argpix && part_param &&
+                    ((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2)),
+                CODON_ERR_BAD_ARG, "cac_bwd_gate: null pointer (dw1 / db1 / dw2 / db2: all four or none)");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_bwd_gate: bad shape");
   return cac_bwd_gate(batch, height, width, part_gch, part_arg, ch, pools, w1, b1, w2, g_pools, argpix, part_param,
                       dw1, db1, dw2, db2, (hipStream_t)stream);
@@ -559,8 +570,7 @@ int codon_cac_bwd_gate(int32_t batch, int32_t height, int32_t width, const float
 int codon_cac_bwd_spatial(int32_t batch, int32_t height, int32_t width, const float* g_z, const float* pooled,
                           const float* w_spatial, float* g_pooled, float* part_w, float* dw_spatial,
                           codon_stream_t stream) {
-  CODON_REQUIRE(g_z && pooled && w_spatial && g_pooled && part_w && dw_spatial, CODON_ERR_BAD_ARG,
-                "cac_bwd_spatial: null pointer");
+  CODON_REQUIRE(g_z && pooled && w_spatial && g_pooled && part_w, CODON_ERR_BAD_ARG, "cac_bwd_spatial: null pointer");
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "cac_bwd_spatial: bad shape");
   return cac_bwd_spatial(batch, height, width, g_z, pooled, w_spatial, g_pooled, part_w, dw_spatial,
                          (hipStream_t)stream);

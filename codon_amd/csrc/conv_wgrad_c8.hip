@@ -683,7 +683,7 @@ int conv2d_wgrad_bf16(const codon_conv_desc* d, const void* x, const void* gy, f
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
   }
   const int st = check_launch("conv_wgrad_c8_kernel");
-  if (st != CODON_OK) return st;
+  if (st != CODON_OK || accumulate == CODON_WGRAD_DEFER) return st;   // DEFER: the splits stay in the workspace (codon_reduce_multi)
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
 }
 
@@ -732,7 +732,7 @@ int conv1x1_bwd_16(const codon_conv_desc* d, const void* x, const void* gy, cons
     else hipLaunchKernelGGL((conv_wgrad_c8_kernel<C8Bf16, 1, true>), grid, dim3(2 * WC8_TH * 64), 0, stream, p);
   }
   const int st = check_launch("conv_wgrad_c8_kernel<1, dgrad>");
-  if (st != CODON_OK) return st;
+  if (st != CODON_OK || accumulate == CODON_WGRAD_DEFER) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, 1, pl.nsplit, accumulate, stream);
 }
 

@@ -262,7 +262,7 @@ int conv2d_wgrad_f32(const codon_conv_desc* d, const float* x, const float* gy, 
   static const bool t16_env = getenv("CODON_WGRAD_T16") ? atoi(getenv("CODON_WGRAD_T16")) != 0 : true;   // 0: round-1 kernel (A/B)
   if (pl.t16 && t16_env && conv_wgrad_f32_t16_supported(d, x, gy)) {
     const int st = launch_wgrad_f32_t16(d, x, gy, workspace, pl.nbands, pl.nsplit, stream);
-    if (st != CODON_OK) return st;
+    if (st != CODON_OK || accumulate == CODON_WGRAD_DEFER) return st;
     return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
   }
   const long HW = (long)d->height * d->width;
@@ -277,7 +277,7 @@ int conv2d_wgrad_f32(const codon_conv_desc* d, const float* x, const float* gy, 
   else if (d->ksize == 3) launch_wgrad<3, 2, 1>(p, pl.nchan_blocks, stream);
   else launch_wgrad<1, 2, 2>(p, pl.nchan_blocks, stream);
   int st = check_launch("conv_wgrad_f32_kernel");
-  if (st != CODON_OK) return st;
+  if (st != CODON_OK || accumulate == CODON_WGRAD_DEFER) return st;
   return launch_wgrad_reduce(workspace, dw, d->cout, d->cin, d->ksize * d->ksize, pl.nsplit, accumulate, stream);
 }
 

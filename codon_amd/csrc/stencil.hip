@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const T* __restrict_
 // of the partial rows, then the 16 group sums are added in order (deterministic).  The round-2 version walked all the
 // rows with 576 threads in three workgroups: 0.63 ms for a 576-value result, longer than the kernel that feeds it.
 __global__ __launch_bounds__(1024) void conv1ch_wgrad_reduce_kernel(const float* __restrict__ part,
-                                                                    float* __restrict__ dw, int nparts, int flip) {
+                                                                    float* __restrict__ dw, int nparts, int flags) {
+  const bool flip = flags & CODON_W1_FLIP, accum = flags & CODON_W1_ACCUMULATE;
   __shared__ float red[16][64];
   const int li = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + li;               // 9 workgroups x 64 = 576
@@ -402,11 +403,13 @@ __global__ __launch_bounds__(1024) void conv1ch_wgrad_reduce_kernel(const float*
     float t = red[0][li];
 #pragma unroll
     for (int k = 1; k < 16; ++k) t += red[k][li];
-    dw[flip ? (i / 9) * 9 + 8 - (i % 9) : i] = t;
+    const int oi = flip ? (i / 9) * 9 + 8 - (i % 9) : i;
+    dw[oi] = accum ? dw[oi] + t : t;
   }
 }
 
 int conv1ch_wgrad_reduce(const float* part, float* dw, int nparts, int flip, hipStream_t stream) {
+  if (flip & CODON_W1_DEFER) return CODON_OK;      // the rows stay in the workspace (codon_reduce_multi)
   hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(9), dim3(1024), 0, stream, part, dw, nparts, flip);
   return check_launch("conv1ch_wgrad_reduce_kernel");
 }

@@ -19,8 +19,17 @@ from .autograd import used_parameters
 
 
 class GradSync:
-    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None):
+    """direct=True (default): `loss.backward()` through CODONNet ADDS the 44 parameter gradients into the .grad views of the
+    flat buffer inside the backward's own kernels (codon_amd.autograd._grad_sink) -- no per-tensor AccumulateGrad add.  What
+    that changes for the caller: `torch.autograd.grad(loss, params)` on such a model returns None for these parameters (use
+    .backward(), or direct=False), and post-accumulate-grad hooks on them do not fire.  Anything that breaks the aliasing
+    (optimizer.zero_grad() with set_to_none=True, a foreign .grad) silently falls back to the ordinary route for that step."""
+
+    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, direct: bool = True):
+        import weakref
         self.group = process_group
+        import os
+        self.direct = bool(direct) and os.environ.get("CODON_GRAD_DIRECT", "1") != "0"      # 0: A/B of the ordinary route
         self.named = used_parameters(model)
         self.params = [p for _, p in self.named]
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -31,8 +40,10 @@ class GradSync:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        self.view_ptrs = [p.grad.data_ptr() for p in self.params]
         self._unused = [p for p in model.parameters() if all(p is not q for q in self.params)]
         self._model = model
+        model.__dict__["_grad_sink"] = weakref.ref(self)      # not a submodule, not pickled (model.__getstate__ drops it)
 
     def _install_views(self):
         off = 0

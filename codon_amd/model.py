@@ -461,12 +461,14 @@ class _CODONBase(nn.Module):
         d = self.__dict__.copy()
         d["_pack_cache"] = {}
         d["_wguard"] = None
+        d.pop("_grad_sink", None)            # a weakref to the GradSync that owns the gradients: per process, per object
         return d
 
     def _replicate_for_data_parallel(self):
         r = super()._replicate_for_data_parallel()
         r._pack_cache = {}
         r._wguard = None
+        r.__dict__.pop("_grad_sink", None)
         # nn.DataParallel builds fresh replicas (fresh weight copies, empty pack cache) for EVERY forward: nothing can be
         # stale in one, and a guard per call would cost a pinned allocation each time
         r._no_guard = True

@@ -259,12 +259,75 @@ def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, 
                                                _ptr(y.buf), _stream(dev)), "conv2d_gated_fwd")
 
 
-def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: bool = False):
-    """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy."""
+class DeferredReduce:
+    """Every fixed-order reduction of a backward pass as ONE launch (codon_reduce_multi).  The producers (weight-gradient
+    kernels, the CAC gate / spatial backward, the 1-channel weight gradients) are called with `defer=(this, key)`: they
+    leave their per-split partials in workspaces this object keeps alive, and run(outs) reduces them all -- the up to five
+    uses of a shared weight in the order they were produced -- writing or ADDING into outs[key].  Bit for bit the values the
+    immediate form (one small reduce launch behind each producer) leaves."""
+
+    def __init__(self):
+        self.wg = {}        # key -> dict(cout, cin, taps, nparts, ws=[...])
+        self.rows = []      # (key, part tensor, element offset, n, nparts, stride, nchunk, flip9)
+
+    def add_wgrad(self, key, ws: torch.Tensor, cout: int, cin: int, taps: int):
+        n = cout * cin * taps
+        assert ws.dtype == torch.float32 and ws.numel() % n == 0
+        e = self.wg.setdefault(key, dict(cout=cout, cin=cin, taps=taps, nparts=ws.numel() // n, ws=[]))
+        assert (e["cout"], e["cin"], e["taps"], e["nparts"]) == (cout, cin, taps, ws.numel() // n), key
+        e["ws"].append(ws)
+
+    def add_rows(self, key, part: torch.Tensor, off: int, n: int, nparts: int, stride: int, nchunk: int = 1, flip9: bool = False):
+        assert part.dtype == torch.float32 and off + (nparts - 1) * stride + n <= part.numel()
+        self.rows.append((key, part, off, n, nparts, stride, nchunk, flip9))
+
+    def keys(self):
+        return list(self.wg.keys()) + [r[0] for r in self.rows]
+
+    def run(self, outs: dict, accumulate: bool):
+        """outs: key -> contiguous fp32 tensor of the gradient's size on the producers' device."""
+        rounds = [[]]               # one launch per round; a weight with more than 5 uses continues in the next round
+        for key, e in self.wg.items():
+            o = outs[key]
+            assert o.dtype == torch.float32 and o.is_contiguous() and o.numel() == e["cout"] * e["cin"] * e["taps"], key
+            uses = e["ws"]
+            for r, u0 in enumerate(range(0, len(uses), L.REDUCE_MAX_USES)):
+                it = L.ReduceItem()
+                it.out = o.data_ptr()
+                chunk = uses[u0:u0 + L.REDUCE_MAX_USES]
+                for j, w_ in enumerate(chunk):
+                    it.part[j] = w_.data_ptr()
+                it.nuse, it.nparts, it.cout, it.cin, it.taps, it.nchunk = len(chunk), e["nparts"], e["cout"], e["cin"], e["taps"], 1
+                it.flags = L.REDUCE_WGRAD | (L.REDUCE_ACCUMULATE if (accumulate or u0 > 0) else 0)
+                while len(rounds) <= r:
+                    rounds.append([])
+                rounds[r].append(it)       # (items of ONE launch run concurrently: two of them must never share `out`)
+        for key, part, off, n, nparts, stride, nchunk, flip9 in self.rows:
+            o = outs[key]
+            assert o.dtype == torch.float32 and o.is_contiguous() and o.numel() == n, key
+            it = L.ReduceItem()
+            it.out = o.data_ptr()
+            it.part[0] = part.data_ptr() + 4 * off
+            it.stride, it.nuse, it.nparts, it.cout, it.cin, it.taps, it.nchunk = stride, 1, nparts, 1, n, 1, nchunk
+            it.flags = (L.REDUCE_ACCUMULATE if accumulate else 0) | (L.REDUCE_FLIP9 if flip9 else 0)
+            rounds[0].append(it)
+        if not rounds[0]:
+            return
+        dev = _dev(*[outs[k] for k in self.keys()])
+        with torch.cuda.device(dev):
+            for items in rounds:
+                arr = (L.ReduceItem * len(items))(*items)
+                L.check(L.load().codon_reduce_multi(arr, len(items), _stream(dev)), "reduce_multi")
+        self.wg, self.rows = {}, []
+
+
+def conv2d_wgrad(x: Slice, gy: Slice, dw: Optional[torch.Tensor], ksize: int, accumulate: bool = False, defer=None):
+    """dw (cout,cin,k,k) fp32 (+)= dL/dw of y = conv(x, w) given gy = dL/dy.  defer = (DeferredReduce, key): the splits
+    stay in the workspace and are reduced by that object's one launch; dw is not used."""
     lib = L.load()
     dev = _dev(x.buf, gy.buf, dw)
     B, H, W = _bhw(x.buf)
-    assert dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, ksize, ksize)
+    assert defer is not None or (dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, ksize, ksize))
     d = L.ConvDesc(B, H, W, x.c, gy.c, ksize, x.ctotal, x.coff, gy.ctotal, gy.coff, 0, 0, 0, _dt(x.buf))
     nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
     if nbytes == 0:
@@ -275,19 +338,25 @@ def conv2d_wgrad(x: Slice, gy: Slice, dw: torch.Tensor, ksize: int, accumulate: 
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        L.check(lib.codon_conv2d_wgrad(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(dw), _ptr(ws), nbytes,
-                                       1 if accumulate else 0, _stream(dev)), "conv2d_wgrad")
+        mode = L.WGRAD_DEFER if defer is not None else (1 if accumulate else 0)
+        L.check(lib.codon_conv2d_wgrad(C.byref(d), _ptr(x.buf), _ptr(gy.buf), None if defer is not None else _ptr(dw),
+                                       _ptr(ws), nbytes, mode, _stream(dev)), "conv2d_wgrad")
         if prof is not None:
             e1.record(torch.cuda.current_stream(dev))
             prof["wgrad_events"].append((e0, e1))
+    if defer is not None:
+        defer[0].add_wgrad(defer[1], ws, gy.c, x.c, ksize * ksize)
 
 
-def conv1x1_bwd(x: Slice, gy: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: torch.Tensor, accumulate: bool = False):
-    """16-bit, 1x1 conv 128 -> 64 on a ReLU output x: dw (+)= dL/dw and gx = (W^T gy) * [x > 0] in one pass over x, gy."""
+def conv1x1_bwd(x: Slice, gy: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: Optional[torch.Tensor],
+                accumulate: bool = False, defer=None):
+    """16-bit, 1x1 conv 128 -> 64 on a ReLU output x: dw (+)= dL/dw and gx = (W^T gy) * [x > 0] in one pass over x, gy.
+    defer: as conv2d_wgrad."""
     lib = L.load()
     dev = _dev(x.buf, gy.buf, w_packed_dgrad, gx.buf, dw)
     B, H, W = _bhw(x.buf)
-    assert dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, 1, 1) and gx.c == x.c and _bhw(gx.buf) == (B, H, W)
+    assert defer is not None or (dw.dtype == torch.float32 and tuple(dw.shape) == (gy.c, x.c, 1, 1))
+    assert gx.c == x.c and _bhw(gx.buf) == (B, H, W)
     assert gx.buf.dtype == x.buf.dtype == gy.buf.dtype and gx.buf.data_ptr() not in (x.buf.data_ptr(), gy.buf.data_ptr())
     d = L.ConvDesc(B, H, W, x.c, gy.c, 1, x.ctotal, x.coff, gy.ctotal, gy.coff, 0, 0, 0, _dt(x.buf))
     nbytes = lib.codon_conv_wgrad_workspace_bytes(C.byref(d))
@@ -296,8 +365,12 @@ def conv1x1_bwd(x: Slice, gy: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     gt = gx.ct()
     with torch.cuda.device(dev):
-        L.check(lib.codon_conv1x1_bwd(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(w_packed_dgrad), C.byref(gt), _ptr(dw),
-                                      _ptr(ws), nbytes, 1 if accumulate else 0, _stream(dev)), "conv1x1_bwd")
+        mode = L.WGRAD_DEFER if defer is not None else (1 if accumulate else 0)
+        L.check(lib.codon_conv1x1_bwd(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(w_packed_dgrad), C.byref(gt),
+                                      None if defer is not None else _ptr(dw), _ptr(ws), nbytes, mode, _stream(dev)),
+                "conv1x1_bwd")
+    if defer is not None:
+        defer[0].add_wgrad(defer[1], ws, gy.c, x.c, 1)
 
 
 def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
@@ -427,17 +500,21 @@ def stencil_1to64(x: torch.Tensor, w: torch.Tensor, y: Slice, relu: bool = False
                 "stencil_1to64")
 
 
-def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: torch.Tensor, flip: bool):
+def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: Optional[torch.Tensor], flip: bool, accumulate: bool = False, defer=None):
+    """The 64 x 9 weight gradient of the stems / the head (include/codon_hip.h); defer: as conv2d_wgrad (a rows item)."""
     lib = L.load()
     dev = _dev(a.buf, s, dw)
     B, H, W = _bhw(a.buf)
-    assert a.c == 64 and dw.numel() == 576 and dw.dtype == torch.float32 and s.shape[1] == 1
+    assert a.c == 64 and s.shape[1] == 1 and (defer is not None or (dw.numel() == 576 and dw.dtype == torch.float32))
     nbytes = lib.codon_conv1ch_wgrad_workspace_bytes(B, H, W)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     at = a.ct()
+    flags = (L.W1_FLIP if flip else 0) | (L.W1_ACCUMULATE if accumulate else 0) | (L.W1_DEFER if defer is not None else 0)
     with torch.cuda.device(dev):
-        L.check(lib.codon_conv1ch_wgrad(B, H, W, C.byref(at), _ptr(s), _ptr(dw), 1 if flip else 0, _ptr(ws), nbytes,
-                                        _dt(a.buf), _stream(dev)), "conv1ch_wgrad")
+        L.check(lib.codon_conv1ch_wgrad(B, H, W, C.byref(at), _ptr(s), None if defer is not None else _ptr(dw), flags,
+                                        _ptr(ws), nbytes, _dt(a.buf), _stream(dev)), "conv1ch_wgrad")
+    if defer is not None:
+        defer[0].add_rows(defer[1], ws, 0, 576, ws.numel() // 576, 576, nchunk=16, flip9=flip)
 
 
 def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] = None, accumulate: bool = True):
@@ -467,9 +544,23 @@ def ew_sum_mask(dst: Slice, srcs, mask: Optional[Slice] = None):
                                       C.byref(mt_) if mt_ is not None else None, _dt(dst.buf), _stream(dev)), "ew_sum_mask")
 
 
+def _cac_param_outputs(defer, B, nsb, part_param, part_w, f32):
+    """The five parameter gradients of a CAC block: fresh tensors for the immediate form, or (defer = (DeferredReduce,
+    (key_w1, key_b1, key_w2, key_b2, key_ws))) rows items over the per-image / per-block partial rows."""
+    if defer is None:
+        return (torch.empty((8, 128), **f32), torch.empty((8,), **f32), torch.empty((64, 8), **f32), torch.empty((64,), **f32),
+                torch.empty((1, 2, 5, 5), **f32))
+    red, keys = defer
+    for key, off, n in zip(keys[:4], (0, 1024, 1032, 1544), (1024, 8, 512, 64)):
+        red.add_rows(key, part_param, off, n, B, 1608)
+    red.add_rows(keys[4], part_w, 0, 50, nsb, 50, nchunk=(1 if nsb < 64 else 64))
+    return (None,) * 5
+
+
 def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
-                 g_pre: Slice, g_pre_c: Slice, g_in: Slice, g_in_c: Slice, accumulate_in: bool):
-    """Full backward of one CAC gate block.  Returns (dw1, db1, dw2, db2, dws) fp32 tensors."""
+                 g_pre: Slice, g_pre_c: Slice, g_in: Slice, g_in_c: Slice, accumulate_in: bool, defer=None):
+    """Full backward of one CAC gate block.  Returns (dw1, db1, dw2, db2, dws) fp32 tensors (None each with `defer`:
+    see _cac_param_outputs)."""
     lib = L.load()
     dev = _dev(g_out.buf, g_out_c.buf, pre.buf, pre_c.buf, ch, sp, pooled, pools, w1, b1, w2, ws, g_pre.buf,
                g_pre_c.buf, g_in.buf, g_in_c.buf)
@@ -483,11 +574,9 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
     g_pools = torch.empty((B, 2, 128), **f32)
     argpix = torch.empty((B, 128), dtype=torch.int32, device=dev)
     part_param = torch.empty((B, 1608), **f32)
-    dw1, db1 = torch.empty((8, 128), **f32), torch.empty((8,), **f32)
-    dw2, db2 = torch.empty((64, 8), **f32), torch.empty((64,), **f32)
     g_pooled = torch.empty((B, 2, H, W), **f32)
     part_w = torch.empty((nsb, 50), **f32)
-    dws = torch.empty((1, 2, 5, 5), **f32)
+    dw1, db1, dw2, db2, dws = _cac_param_outputs(defer, B, nsb, part_param, part_w, f32)
     t = [s.ct() for s in (g_out, g_out_c, pre, pre_c, g_pre, g_pre_c, g_in, g_in_c)]
     st = _stream(dev)
     with torch.cuda.device(dev):
@@ -507,7 +596,7 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
 
 
 def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp, pooled, pools, w1, b1, w2, ws,
-                       g_in: Slice, g_in_c: Slice, accumulate_in: bool):
+                       g_in: Slice, g_in_c: Slice, accumulate_in: bool, defer=None):
     """16-bit tensors, training: the CAC gate backward WITHOUT the apply pass.  Pass A also records every pixel's arg-max
     channel and folds g_out into g_in (codon_cac_bwd_reduce_acc); dL/d(pre) is not materialised -- conv1x1_bwd_gated forms
     it from g_out while staging.  Returns (dw1, db1, dw2, db2, dws, gate) with gate = the operands conv1x1_bwd_gated needs.
@@ -527,11 +616,9 @@ def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, c
     g_pools = torch.empty((B, 2, 128), **f32)
     argpix = torch.empty((B, 128), **i32)
     part_param = torch.empty((B, 1608), **f32)
-    dw1, db1 = torch.empty((8, 128), **f32), torch.empty((8,), **f32)
-    dw2, db2 = torch.empty((64, 8), **f32), torch.empty((64,), **f32)
     g_pooled = torch.empty((B, 2, H, W), **f32)
     part_w = torch.empty((nsb, 50), **f32)
-    dws = torch.empty((1, 2, 5, 5), **f32)
+    dw1, db1, dw2, db2, dws = _cac_param_outputs(defer, B, nsb, part_param, part_w, f32)
     t = [s_.ct() for s_ in (g_out, g_out_c, pre, pre_c, g_in, g_in_c)]
     st = _stream(dev)
     with torch.cuda.device(dev):
@@ -548,14 +635,15 @@ def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, c
     return dw1, db1, dw2, db2, dws, gate
 
 
-def conv1x1_bwd_gated(x: Slice, g_out: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: torch.Tensor, gate: dict,
-                      fcat_base: int, accumulate: bool = False):
+def conv1x1_bwd_gated(x: Slice, g_out: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw: Optional[torch.Tensor], gate: dict,
+                      fcat_base: int, accumulate: bool = False, defer=None):
     """conv1x1_bwd whose output gradient dL/d(pre) is formed from the block's dL/d(out) `g_out` (one stream's 64 channels)
     while it is staged -- see cac_backward_fused.  fcat_base: 0 = colour stream (confuse_c), 64 = depth stream (confuse)."""
     lib = L.load()
     dev = _dev(x.buf, g_out.buf, w_packed_dgrad, gx.buf, dw, *gate.values())
     B, H, W = _bhw(x.buf)
-    assert dw.dtype == torch.float32 and tuple(dw.shape) == (g_out.c, x.c, 1, 1) and gx.c == x.c and _bhw(gx.buf) == (B, H, W)
+    assert defer is not None or (dw.dtype == torch.float32 and tuple(dw.shape) == (g_out.c, x.c, 1, 1))
+    assert gx.c == x.c and _bhw(gx.buf) == (B, H, W)
     assert gx.buf.dtype == x.buf.dtype == g_out.buf.dtype and gx.buf.data_ptr() not in (x.buf.data_ptr(), g_out.buf.data_ptr())
     assert tuple(gate["argch"].shape) == (B, H, W) and gate["argch"].dtype == torch.int32
     d = L.ConvDesc(B, H, W, x.c, g_out.c, 1, x.ctotal, x.coff, g_out.ctotal, g_out.coff, 0, 0, 0, _dt(x.buf))
@@ -565,8 +653,11 @@ def conv1x1_bwd_gated(x: Slice, g_out: Slice, w_packed_dgrad: torch.Tensor, gx: 
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     gt = gx.ct()
     with torch.cuda.device(dev):
+        mode = L.WGRAD_DEFER if defer is not None else (1 if accumulate else 0)
         L.check(lib.codon_conv1x1_bwd_gated(C.byref(d), _ptr(x.buf), _ptr(g_out.buf), _ptr(w_packed_dgrad), C.byref(gt),
-                                            _ptr(dw), _ptr(ws), nbytes, 1 if accumulate else 0, _ptr(gate["ch"]),
+                                            None if defer is not None else _ptr(dw), _ptr(ws), nbytes, mode, _ptr(gate["ch"]),
                                             _ptr(gate["sp"]), _ptr(gate["g_pooled"]), _ptr(gate["g_pools"]),
                                             _ptr(gate["argpix"]), _ptr(gate["argch"]), fcat_base, _stream(dev)),
                 "conv1x1_bwd_gated")
+    if defer is not None:
+        defer[0].add_wgrad(defer[1], ws, g_out.c, x.c, 1)

@@ -171,8 +171,11 @@ int codon_conv2d_gated_emit_fwd(const codon_conv_desc* d, const void* pre, const
  * computes for the nn.Conv2d weights (the reference has no explicit backward).
  * d describes the FORWARD conv: x = its input (x_* fields), gy = gradient of its output (y_* fields
  * describe gy's buffer).  workspace: codon_conv_wgrad_workspace_bytes(d) bytes of scratch (per-split
- * partials, summed in fixed order: deterministic).  The result is ADDED into dw when accumulate != 0
- * (weights shared by the 5 / 3 loop iterations, CODON_x4.py:74,122). */
+ * partials, summed in fixed order: deterministic).  accumulate: 0 = dw is overwritten; 1 = the result is ADDED into dw
+ * (weights shared by the 5 / 3 loop iterations, CODON_x4.py:74,122); CODON_WGRAD_DEFER = the per-split partials
+ * [nsplit][k*k][cout][cin] (nsplit = workspace bytes / (4 k k cout cin)) are LEFT in `workspace` for a later
+ * codon_reduce_multi -- one launch for all the weight gradients of a backward pass -- and dw is not touched (may be NULL). */
+#define CODON_WGRAD_DEFER 2
 size_t codon_conv_wgrad_workspace_bytes(const codon_conv_desc* d);
 int codon_conv2d_wgrad(const codon_conv_desc* d, const void* x, const void* gy, float* dw,
                        void* workspace, size_t workspace_bytes, int32_t accumulate,
@@ -265,6 +268,12 @@ int codon_stencil_1to64(int32_t batch, int32_t height, int32_t width, const floa
 /* dw[c*9 + t] = sum_{b,q} a[b,c,q] * s[b, q + (t/3-1, t%3-1)]   (flip: written at c*9 + 8-t)
  * stem: a = dL/d(stem output, ReLU-masked), s = x, flip=0  -> input.weight.grad (64,1,3,3)
  * head: a = t11, s = dL/dy, flip=1                         -> output.weight.grad (1,64,3,3) */
+/* flip: bit 0 = flipped taps; bit 1 (CODON_W1_ACCUMULATE) = dw += ...; bit 2 (CODON_W1_DEFER) = the (nparts, 576) partial
+ * rows, nparts = workspace bytes / 2304, stay in `workspace` for codon_reduce_multi (rows item: nchunk 16, FLIP9 for the
+ * head) and dw is not touched (may be NULL). */
+#define CODON_W1_FLIP 1
+#define CODON_W1_ACCUMULATE 2
+#define CODON_W1_DEFER 4
 size_t codon_conv1ch_wgrad_workspace_bytes(int32_t batch, int32_t height, int32_t width);
 int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codon_tensor* a,
                         const float* s, float* dw, int32_t flip, void* workspace,
@@ -285,9 +294,11 @@ int codon_ew_sum_mask(int32_t batch, int32_t height, int32_t width, int32_t chan
  * reduce : g_z (B,1,H,W) = dL/d(spatial logits); part_gch (B,nt,64), part_arg (B,nt,128) int32,
  *          nt = codon_cac_bwd_tiles(H,W).  pools = the (B,2,128) {avg,max} saved by cac_gate_fwd.
  * gate   : g_pools (B,2,128) = dL/d{avg,max}; argpix (B,128) int32 first arg-max pixel of each Fcat
- *          channel; part_param (B,1608) scratch; dw1 (8,128), db1 (8), dw2 (64,8), db2 (64) OVERWRITTEN.
+ *          channel; part_param (B,1608) scratch; dw1 (8,128), db1 (8), dw2 (64,8), db2 (64) OVERWRITTEN -- or all four
+ *          NULL: the per-image rows w1 | b1 | w2 | b2 (offsets 0, 1024, 1032, 1544) stay in part_param for codon_reduce_multi.
  * spatial: g_pooled (B,2,H,W) = dL/d{chmax,chmean}; part_w (codon_cac_bwd_spatial_blocks(B,H,W),50)
- *          scratch; dw (1,2,5,5) OVERWRITTEN.
+ *          scratch; dw (1,2,5,5) OVERWRITTEN -- or NULL: the rows stay in part_w for codon_reduce_multi (nchunk 64 when
+ *          there are >= 64 rows, else 1: the order of the immediate form).
  * apply  : g_pre / g_pre_c = full dL/dpre, dL/dpre_c; g_in / g_in_c (+)= g_out / g_out_c
  *          (accumulate_in = 0 writes instead of adding). */
 int32_t codon_cac_bwd_tiles(int32_t height, int32_t width);
@@ -320,6 +331,36 @@ int codon_cac_bwd_apply(int32_t batch, int32_t height, int32_t width, const codo
                         const float* g_pools, const int32_t* argpix, const codon_tensor* g_pre,
                         const codon_tensor* g_pre_c, const codon_tensor* g_in, const codon_tensor* g_in_c,
                         int32_t accumulate_in, int32_t dtype, codon_stream_t stream);
+
+/* ---- every deferred fixed-order reduction of a backward pass in ONE launch ---------------------------------------
+ * Parameter gradients of autograd through CODON_x4.py:66-132 (the reference has no explicit backward) leave
+ * their kernels as partial sums; instead of one small reduce launch behind each producer (86 per training step) the caller
+ * collects them as items and reduces them all at once, optionally ADDING into its own gradient storage (a slice of the flat
+ * data-parallel all-reduce buffer: no per-tensor add afterwards).  Every sum runs in a fixed order.
+ *   WGRAD item : out (cout,cin,k,k) (+)= r_0 + r_1 + ... + r_{nuse-1} (added in that order; the 5 / 3 uses of a shared weight),
+ *                r_u = sum_s part[u][s][tap][co][ci] over nparts splits, serially from zero: the CODON_WGRAD_DEFER
+ *                workspaces.  Bit for bit what nuse immediate calls (accumulate = 1 on all but the first) produce.
+ *                cin % 4 == 0, workspaces 16-byte aligned; taps = k*k.
+ *   rows item  : out[f(i)] (+)= sum_k part[0][k*stride + i], i < cin (= the row length; cout = taps = 1), nparts rows.
+ *                nchunk 1: serial; 16 or 64: two-level -- chunk c = rows [c*per, (c+1)*per), per = ceil(nparts/nchunk),
+ *                summed serially, then the chunk sums in order.  CODON_REDUCE_FLIP9: f(i) = (i/9)*9 + 8 - i%9.
+ * flags: CODON_REDUCE_ACCUMULATE adds into out instead of overwriting.  The items of one call run CONCURRENTLY: no two of them
+ * may share `out` (a weight with more than CODON_REDUCE_MAX_USES uses continues in a second call with ACCUMULATE). */
+#define CODON_REDUCE_MAX_USES 5
+#define CODON_REDUCE_MAX_ITEMS 44
+enum { CODON_REDUCE_ACCUMULATE = 1, CODON_REDUCE_WGRAD = 2, CODON_REDUCE_FLIP9 = 4 };
+typedef struct codon_reduce_item {
+  float* out;
+  const float* part[CODON_REDUCE_MAX_USES];
+  int64_t stride;   /* rows item: floats between consecutive rows */
+  int32_t nuse;     /* WGRAD item: workspaces in part[] (1..CODON_REDUCE_MAX_USES) */
+  int32_t nparts;   /* splits per workspace / rows */
+  int32_t cout, cin, taps;
+  int32_t nchunk;   /* rows item: 1, 16 or 64 */
+  int32_t flags;
+  int32_t reserved;
+} codon_reduce_item;
+int codon_reduce_multi(const codon_reduce_item* items, int32_t n_items, codon_stream_t stream);
 
 /* ---- either side of the network in the reference's script ----------------------------
  * postprocess_u8 : out[i] = (uint8)(clip(x[i],0,1) * 255)  (truncating)      CODON_X4/test.py:127-132

@@ -495,6 +495,37 @@ def test_training_schedules_agree_bit_for_bit():
         A.SUM_IN_DGRAD = olds
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], g5[n]), n
+    # ... and every reduction of the backward in one launch at its end, or a small launch behind each producer (round 5)
+    oldd = A.DEFER_REDUCE
+    try:
+        A.DEFER_REDUCE = not oldd
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g6 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.DEFER_REDUCE = oldd
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], g6[n]), n
+    # ... dL/d(fuse) collected by the trunk's input-gradient convs (round 5) or by ew_sum_mask: NOT the same roundings -- the
+    # running sum is stored in bf16 after each term (as the reference's own bf16 autograd accumulates, and as dL/d(inputs)
+    # does above), the pass rounded the fp32 sum of four terms once -- so everything downstream of dL/d(fuse) agrees to bf16
+    # rounding noise, everything upstream (the trunk, conv11, output) bit for bit
+    oldg = A.SUM_GFUSE_IN_DGRAD
+    try:
+        A.SUM_GFUSE_IN_DGRAD = not oldg
+        net.zero_grad(set_to_none=True)
+        out = net(x, y)
+        out.backward(gy)
+        g7 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        A.SUM_GFUSE_IN_DGRAD = oldg
+    for n in res[0][1]:
+        if n.split(".")[0] in ("conv8", "conv9", "conv10", "confuse_fuse", "conv11", "output"):
+            assert torch.equal(res[0][1][n], g7[n]), n
+        else:
+            a, b_ = res[0][1][n].double(), g7[n].double()
+            assert float((a - b_).norm() / b_.norm()) < 2e-2, (n, float((a - b_).norm() / b_.norm()))
 
 
 @pytest.mark.parametrize("dtype", DT)
