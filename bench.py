@@ -77,6 +77,99 @@ def pmc_traffic(kernel_prefix, B, H, W, pattern="r*_fwd_b32_480x640_pmc*.json"):
     return None
 
 
+def pmc_traffic_hash(pattern="r*_fwd_b32_480x640_pmc*.json"):
+    """(library source hash the newest committed PMC table of `pattern` was taken from, hash of the library loaded now):
+    printed beside roofline.traffic so that a ratio measured on an older build of the kernels is visible from the line."""
+    import glob
+    from codon_amd import _lib
+    now = _lib.build_info()["source_hash_built"]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        if "_before_" in os.path.basename(path):
+            continue
+        try:
+            return json.load(open(path)).get("lib_source_hash"), now
+        except (OSError, ValueError):
+            continue
+    return None, now
+
+
+class HwmonSampler:
+    """Socket power and shader clock of THIS rank's card during a timed region (hwmon sysfs: power1_average / power1_input,
+    freq1_input, power1_cap), sampled every 50 ms by a host thread that never touches the GPU.  A node-level power budget
+    -- 8 sockets that each sit at their 1400 W cap when alone -- shows up in the rank records as lower clocks instead of as
+    an unexplained loss of weak-scaling efficiency.  The card is found by PCI address (torch's pci_bus_id against the sysfs
+    device link); if that fails (no sysfs, a container that hides it) the fields are null -- except with ONE rank, where the
+    card that draws the most power during the region is taken (the box shows every card of the host)."""
+
+    def __init__(self, dev):
+        import glob
+        self.hws = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if glob.glob(h + "/power1_*")]
+        self.mine = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for h in self.hws:
+                if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).startswith(want):
+                    self.mine = h
+        except Exception:                      # noqa: BLE001 -- telemetry must never fail the bench
+            pass
+        self.rows = {h: [] for h in self.hws}
+        self._stop = None
+        self._th = None
+
+    @staticmethod
+    def _rd(path):
+        try:
+            return float(open(path).read())
+        except Exception:                      # noqa: BLE001
+            return float("nan")
+
+    def start(self):
+        import threading
+        if not self.hws:
+            return self
+        self._stop = threading.Event()
+        cards = [self.mine] if self.mine else self.hws
+
+        def run():
+            while not self._stop.is_set():
+                for h in cards:
+                    pw = self._rd(h + "/power1_average")
+                    if pw != pw:
+                        pw = self._rd(h + "/power1_input")
+                    self.rows[h].append((pw / 1e6, self._rd(h + "/freq1_input") / 1e6))
+                self._stop.wait(0.05)
+
+        self._th = threading.Thread(target=run, name="hwmon", daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self, single_rank=True):
+        out = {"power_w_p50": None, "power_w_p95": None, "sclk_mhz_p50": None, "power_cap_w": None, "hwmon_samples": 0,
+               "hwmon_matched_by": None}
+        if self._th is None:
+            return out
+        self._stop.set()
+        self._th.join(1.0)
+        h = self.mine
+        how = "pci address"
+        if h is None and single_rank:
+            mean = {k: (sum(r[0] for r in v if r[0] == r[0]) / max(1, len(v))) for k, v in self.rows.items()}
+            h = max(mean, key=mean.get) if mean else None
+            how = "highest draw (one rank)"
+        if h is None or not self.rows[h]:
+            return out
+        pw = sorted(r[0] for r in self.rows[h] if r[0] == r[0])
+        fq = sorted(r[1] for r in self.rows[h] if r[1] == r[1])
+        cap = self._rd(h + "/power1_cap") / 1e6
+        if pw:
+            out.update(power_w_p50=pw[len(pw) // 2], power_w_p95=pw[int(len(pw) * 0.95)], hwmon_samples=len(pw))
+        if fq:
+            out.update(sclk_mhz_p50=fq[len(fq) // 2])
+        out.update(power_cap_w=cap if cap == cap else None, hwmon_matched_by=how)
+        return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -121,16 +214,17 @@ def cpu_baseline(H, W):
             orc.forward(sd, x1, y1)
             c1.append(time.perf_counter() - t0)
         full = []
-        for _ in range(3):                       # ~6 s each on 16 threads: bounded at ~20 s
+        orc.forward(sd, x, y)                    # 1 warm-up + 5 runs, ~6 s each on 16 threads: ~35 s
+        for _ in range(5):
             t0 = time.perf_counter()
             orc.forward(sd, x, y)
             full.append(time.perf_counter() - t0)
     c1.sort()
     full.sort()
-    dt = full[1]
+    dt = full[2]
     return {"value": 1.0 / dt, "unit": "maps/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
             "host_cores_visible": avail, "kind": "port",
-            "sample": f"1 image (1x1x{H}x{W} pair) of the batch, 3 oracle forwards: median {dt:.1f} s, min {full[0]:.1f} s",
+            "sample": f"1 image (1x1x{H}x{W} pair) of the batch, 1 warm-up + 5 oracle forwards: median {dt:.1f} s, min {full[0]:.1f} s",
             "mpx_per_s": H * W / dt / 1e6,
             "config0_1x128x128": {"min_s": c1[0], "median_s": c1[2], "runs": 5}}
 
@@ -222,7 +316,9 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
     # live roofline of the dominant backward kernel: HIP events around every conv5x5 128->128 weight-gradient launch
     ops.PROFILE = {"key": None, "events": [], "wgrad_key": (5, 128, 128), "wgrad_events": []}
     evs = []
+    hw = HwmonSampler(dev)
     barrier()
+    hw.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -232,6 +328,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
         evs.append((e0, e1))
     barrier()
     dt = time.perf_counter() - t0
+    hw_train = hw.stop(single_rank=(world == 1))
     prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(loss)
     # one all-reduce of the flat gradient, timed on its own (latency-bound: 7.46 MB over xGMI)
@@ -247,6 +344,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
         ar_us = (time.perf_counter() - t1) / 10 * 1e6
     dt = max_over_ranks(dt, dist, ctrl)
     per_rank = gather_rank_info(step_stats(evs), dist, rank, world, ctrl)
+    hw_ranks = gather_rank_info(hw_train, dist, rank, world, ctrl)
     model.check_packed(synchronize=False)
     if rank != 0:
         return None
@@ -270,6 +368,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "images_per_s": world * B * steps / dt,
             "step_events": step_stats(evs),
             "per_rank_step_ms": [{k: st_[k] for k in ("median_ms", "min_ms", "max_ms")} if st_ else None for st_ in per_rank],
+            "per_rank_hwmon": hw_ranks,
             "whole_step": {"tflops": tf, "frac_mfma_peak": tf / peak,
                            "flop_model": "3 x forward FLOPs (SURVEY.md 8d: dgrad + wgrad per conv)"},
             "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_c8_kernel<5>" if dtype == "bf16" else "conv_wgrad_f32_t16_kernel<5>") +
@@ -279,6 +378,8 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
                                                 "r*_bf16_train_b32_480x640_pmc.json") if dtype == "bf16" else None,
                          "traffic_note": "PMC bytes per launch of the 128->128 launches only (the kernel name carries the shape)",
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic_from_hash": pmc_traffic_hash("r*_bf16_train_b32_480x640_pmc.json")[0] if dtype == "bf16" else None,
+                         "lib_source_hash": pmc_traffic_hash()[1],
                          "alg_bytes_per_launch": 2 * 128 * esz * P, "launches_timed": len(wev), "avg_launch_ms": wms,
                          "flop_per_launch": wflop},
             "allreduce_us": ar_us, "allreduce_bytes": gs.numel * 4,
@@ -577,7 +678,9 @@ def main():
         ops.PROFILE = {"key": (5, 128, 128), "events": []}
         dtype_label = "f32 via 3xf16-split MFMA (opt-in, not exact fp32)" if split else a.dtype
         step_ev = []
+        hw = HwmonSampler(dev)
         barrier()
+        hw.start()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -587,11 +690,13 @@ def main():
             step_ev.append((e0, e1))
         barrier()
         dt = time.perf_counter() - t0
+        hw_fwd = hw.stop(single_rank=(world == 1))
         prof, ops.PROFILE = ops.PROFILE, None
     assert torch.isfinite(out).all()
 
     dt = max_over_ranks(dt, dist, ctrl)
     fwd_per_rank = gather_rank_info(step_stats(step_ev), dist, rank, world, ctrl)   # a straggler GPU shows up per rank
+    hw_per_rank = gather_rank_info(hw_fwd, dist, rank, world, ctrl)                 # ... and a capped socket as a lower clock
 
     res = None
     if rank == 0:
@@ -626,6 +731,9 @@ def main():
                                                  "r*_bf16_fwd_b32_480x640_pmc.json") if bf16 else
                                      None if split else pmc_traffic("codon::conv_mfma_f32_kernel<5, 128, 128", B, H, W)),
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic_from_hash": None if split else pmc_traffic_hash(
+                             "r*_bf16_fwd_b32_480x640_pmc.json" if bf16 else "r*_fwd_b32_480x640_pmc*.json")[0],
+                         "lib_source_hash": pmc_traffic_hash()[1],
                          "alg_bytes_per_launch": (128 + 64 if chained else 2 * 128) * esize * P,
                          "launches_timed": len(ev), "avg_launch_ms": kms,
                          "flop_per_launch": kflop},
@@ -661,8 +769,9 @@ def main():
         res["control_backend"] = None if dist is None else "gloo"
         if probe is not None:
             res["rccl_probe"] = probe
-        for r_, st_ in zip(ranks, fwd_per_rank):
+        for r_, st_, hw_ in zip(ranks, fwd_per_rank, hw_per_rank):
             r_["fwd_step_ms"] = {k: st_[k] for k in ("median_ms", "min_ms", "max_ms")} if st_ else None
+            r_.update(hw_)           # power_w_p50 / power_w_p95 / sclk_mhz_p50 / power_cap_w of the forward's timed region
         res["ranks"], res["versions"] = ranks, versions
         if selfcheck is not None:
             res["grad_equal"], res["rccl_selfcheck"] = selfcheck["grad_equal"], selfcheck
@@ -699,8 +808,9 @@ def main():
                               "peak_mem_gb": leg["peak_mem_gb"], "step_events": leg["step_events"],
                               "roofline": leg["roofline"], "allreduce_us": leg["allreduce_us"],
                               "allreduce_bytes": leg["allreduce_bytes"], "scaling": leg["scaling"]}
-            for r_, st_ in zip(res["ranks"], leg["per_rank_step_ms"]):
+            for r_, st_, hw_ in zip(res["ranks"], leg["per_rank_step_ms"], leg["per_rank_hwmon"]):
                 r_["train_step_ms"] = st_
+                r_["train_power_w_p50"], r_["train_sclk_mhz_p50"] = hw_["power_w_p50"], hw_["sclk_mhz_p50"]
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, W)

@@ -131,7 +131,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), s
         for n, p in named:
             G[n] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
-    acc0 = sink is not None                        # the first contribution to a gradient adds (sink) or overwrites
+    add0 = sink is not None                        # the first contribution to a gradient adds (sink) or overwrites
     red = ops.DeferredReduce() if DEFER_REDUCE else None
     started = set()                                # immediate form: gradients that hold their first contribution
 
@@ -165,7 +165,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), s
             ops.conv2d(gs, Pd(name), gxs, 1, relu_mask=xs)
             return
         key = name + ".weight"
-        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0 or key in started)
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=add0 or key in started)
         started.add(key)
         if gate is not None:
             ops.conv1x1_bwd_gated(xs, gs, Pd(name), gxs, G[key], gate, fcat_base, **kw)
@@ -174,13 +174,13 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), s
 
     def wgrad(name, xs: Slice, gs: Slice, k: int):
         key = name + ".weight"
-        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0 or key in started)
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=add0 or key in started)
         started.add(key)
         ops.conv2d_wgrad(xs, gs, G[key], k, **kw)
 
     def wgrad1ch(name, a: Slice, img, flip: bool):
         key = name + ".weight"
-        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=acc0)
+        kw = dict(defer=(red, key)) if red is not None else dict(accumulate=add0)
         ops.conv1ch_wgrad(a, img, G[key], flip=flip, **kw)
 
     # ---- tail: y_hat = output(t11) + x ; t11 = relu(conv11(f3))                       :129-131
@@ -274,7 +274,7 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), s
                 accumulate_in=(i != 4), **cdefer)
         if red is None:             # immediate form (A/B): the five small results go to their places by five small copies / adds
             for key, t_ in zip(ckeys, (dw1, db1, dw2, db2, dws)):
-                G[key].add_(t_.view_as(G[key])) if acc0 else G[key].copy_(t_.view_as(G[key]))
+                G[key].add_(t_.view_as(G[key])) if add0 else G[key].copy_(t_.view_as(G[key]))
         # block input gradient: blocks 1..4 read oc_{i-1}; block 0 reads in2 (accumulate there)
         if i > 0:
             # g_oc is dead after this block's cac_backward + 1x1 backward launches: reuse it (unless it just became g_in2)
@@ -337,5 +337,5 @@ def _backward_impl(model, S, x, y, gy, debug=None, input_grads=(False, False), s
             ops.head(Slice(g_s), wt, gy if off == 0 else torch.zeros_like(gy), g_img)
             G["__input_c" if off else "__input"] = g_img
     if red is not None:
-        red.run(G, accumulate=acc0)
+        red.run(G, accumulate=add0)
     return G

@@ -84,10 +84,6 @@ __device__ __forceinline__ u32x4 c8_pack(const float (&v)[8]) {
   return q;
 }
 
-// cache policy of every channel-blocked activation store (A/B): 0 = default, 2 = nt (streaming), 1 = sc0, 16 = sc1
-#ifndef CODON_C8_ST_AUX
-#define CODON_C8_ST_AUX 0
-#endif
 __device__ __forceinline__ u32x4 c8_ld(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return *reinterpret_cast<const u32x4*>(&v);
@@ -101,7 +97,7 @@ __device__ __forceinline__ u32x4 c8_ld(const __amdgpu_buffer_rsrc_t r, unsigned 
 // wait states are pinned behind the store; they cost nothing beside 16 bytes per lane of memory traffic.
 __device__ __forceinline__ void c8_st(const u32x4 q, const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0u, 0u, 0)) raw_t;
-  __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const raw_t*>(&q), r, voff, soff, CODON_C8_ST_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const raw_t*>(&q), r, voff, soff, 0);   // default cache policy (nt / sc0 / sc1 stores measured in round 4: no gain)
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 1");
   __builtin_amdgcn_sched_barrier(0);

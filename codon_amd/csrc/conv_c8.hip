@@ -73,31 +73,12 @@ enum { RESC8_NONE = 0, RESC8_ADD = 1, RESC8_MASK = 2, RESC8_SUMINTO = 3 };
 constexpr int CONV_C8_SUM_INTO = 1 << 16;
 
 // pixel rows per wave: the 5x5 64-cout kernel takes 4 (16x32 tile) so that, like the 128-cout ones, a filter tap is
-// 8 MFMAs on 6 operand fetches
-#ifndef CODON_C8_PSEG3
-#define CODON_C8_PSEG3 2
-#endif
-#ifndef CODON_C8_OCC3
-#define CODON_C8_OCC3 2
-#endif
-#ifndef CODON_C8_NW5128
-#define CODON_C8_NW5128 4
-#endif
-#ifndef CODON_C8_NW564
-#define CODON_C8_NW564 4
-#endif
-#ifndef CODON_C8_NW364
-#define CODON_C8_NW364 4
-#endif
-#ifndef CODON_C8_XEARLY
-#define CODON_C8_XEARLY 1  // resident-filter kernel: request the next chunk's halo tile a whole chunk ahead (0: one / two stages, A/B)
-#endif
-#ifndef CODON_C8_DMA
-#define CODON_C8_DMA 1     // stage x and weights by LDS-DMA (buffer_load_dwordx4 ... lds); 0: through registers (A/B)
-#endif
-template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : (COUT == 64 && KS == 3) ? CODON_C8_PSEG3 : 2; };
-// waves per workgroup: NW = 8 stages one weight image for a 2x taller tile (half the weight bytes per MFMA), one workgroup per CU
-template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS == 5 && COUT == 128) ? CODON_C8_NW5128 : (KS == 5 && COUT == 64) ? CODON_C8_NW564 : (KS == 3 && COUT == 64) ? CODON_C8_NW364 : 4; };
+// 8 MFMAs on 6 operand fetches.  (Measured and settled, profiles/HISTORY.md: 16x32 tiles for the 3x3 convs, 8-wave
+// workgroups for any of the shapes, staging through registers instead of LDS-DMA -- all slower; the switches are gone.)
+constexpr bool C8_DMA = true;     // x and weights go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds); GATE kernels stage x through registers
+template <int KS, int COUT> struct ConvC8Pseg { static constexpr int value = (COUT == 64 && KS == 5) ? 4 : 2; };
+// waves per workgroup of the staged kernels (the resident-filter conv3x3 runs 16)
+template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = 4; };
 
 // PERSIST (round 4): a workgroup walks a contiguous RANGE of tiles instead of one.  The stage pipeline simply continues
 // across the tile edge: the last stage of tile t requests stage 0 of tile t+1 (its first halo chunk through tile t+1's
@@ -109,8 +90,8 @@ template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = (KS =
 // per-chunk traffic left is the halo tile, and the only barrier the one that publishes it (per chunk, not per stage).
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
           bool RESW = false>
-__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CODON_C8_OCC3 : 2)) void conv_c8_kernel(const ConvC8Params p) {
-  static_assert(!PERSIST || (!FUSE && !GATE && CODON_C8_DMA != 0), "the tile loop exists for the plain LDS-DMA convs");
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(const ConvC8Params p) {
+  static_assert(!PERSIST || (!FUSE && !GATE && C8_DMA), "the tile loop exists for the plain LDS-DMA convs");
   static_assert(!RESW || PERSIST, "a resident filter pays only over many tiles");
   typedef typename E::vec8 vec8;
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
@@ -229,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CO
 
   // the next chunk's halo tile is requested in two halves, during the last two filter rows of the current chunk
   constexpr int XE1 = XE / 2, XEH = XE - XE1;
-  constexpr bool DMA = (CODON_C8_DMA != 0) && !GATE;
+  constexpr bool DMA = C8_DMA && !GATE;
   typedef __attribute__((address_space(3))) void lds_void;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   u32x4 xv[DMA ? 1 : XEH];
@@ -361,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : (KS == 3 && COUT == 64) ? CO
       // a whole chunk of lead instead of one or two stages.  (Counters on the 3x3 kernels, tools/probes/pmc_conv3.sh: waves
       // parked at s_waitcnt / barrier 52-55 % of their cycles against 9-13 % in the 5x5 kernels -- with 12 MFMAs per stage a
       // tile half requested at the start of the chunk's last stage has 0.2 us to cross the memory system.)
-      constexpr bool XEARLY = RESW && CODON_C8_XEARLY != 0;
+      constexpr bool XEARLY = RESW;
       if constexpr (XEARLY && dy == 0) {
         if (!(par == 1 && c2 + 2 >= NCHUNK)) { LOAD_X(chunk + 1, par ^ 1, 0, XE); }
         else if (wrap) { LOAD_X(0, par ^ 1, 0, XE); }
@@ -928,24 +909,11 @@ static int c8_resident_blocks(K kernel, int threads) {
   return v;
 }
 
-// PERSIST launches: one resident generation of workgroups, each walking >= C8_PERSIST_MIN_TILES tiles; smaller problems
-// keep one tile per workgroup (nothing to amortise, and the small-grid latency path wants many short workgroups)
-#ifndef CODON_C8_PERSIST3
-#define CODON_C8_PERSIST3 0        // plain conv3x3 64->64 through the tile loop with STAGED weights (measured: no gain)
-#endif
-#ifndef CODON_C8_PERSIST5
-#define CODON_C8_PERSIST5 0        // plain conv5x5 64->64 likewise
-#endif
-constexpr int C8_PERSIST_MIN_TILES = 4;
-#ifndef CODON_C8_RESIDENT3
-#define CODON_C8_RESIDENT3 1       // plain conv3x3 64->64 with the whole filter resident in LDS (0: the staged kernel, A/B)
-#endif
+// The resident-filter conv3x3 64->64 is a PERSIST launch: one resident generation of workgroups, each walking at least
+// C8_RESIDENT_MIN_TILES tiles; smaller problems keep one tile per workgroup (nothing to amortise, and the small-grid latency
+// path wants many short workgroups).  (The tile loop with STAGED weights, for the plain 3x3 and 5x5 64->64 convs, was
+// measured as a loss and is gone: tools/probes/conv_c8_persist_staged_experiment.patch, profiles/HISTORY.md.)
 constexpr int C8_RESIDENT_MIN_TILES = 8;
-template <int KS, int CIN, int COUT, bool FUSE, bool GATE> struct ConvC8Persist {
-  static constexpr bool value = !FUSE && !GATE && CODON_C8_DMA != 0 && CIN == 64 && COUT == 64 &&
-                                ((KS == 3 && CODON_C8_PERSIST3 != 0) || (KS == 5 && CODON_C8_PERSIST5 != 0));
-};
-
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
@@ -955,7 +923,7 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
   p.nblk = (int)nblk;
-  if constexpr (KS == 3 && CIN == 64 && COUT == 64 && !FUSE && !GATE && CODON_C8_DMA != 0 && CODON_C8_RESIDENT3 != 0) {
+  if constexpr (KS == 3 && CIN == 64 && COUT == 64 && !FUSE && !GATE && C8_DMA) {
     // resident-filter persistent form: 16 waves, 32 x 32 tiles, one workgroup per CU
     constexpr int NWR = 16, THR = NWR * ConvC8Pseg<KS, COUT>::value;
     constexpr bool RW = true;
@@ -969,14 +937,6 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
       hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NWR, GATE, true, RW>), dim3((unsigned)res), dim3(64 * NWR), 0,
                          stream, pr);
       return check_launch("conv_c8_kernel<resident>");
-    }
-  }
-  if constexpr (ConvC8Persist<KS, CIN, COUT, FUSE, GATE>::value) {
-    const int res = c8_resident_blocks(conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, true>, 64 * NW);
-    if (res > 0 && nblk >= (long)res * C8_PERSIST_MIN_TILES) {
-      hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, true>), dim3((unsigned)res), dim3(64 * NW), 0,
-                         stream, p);
-      return check_launch("conv_c8_kernel<persistent>");
     }
   }
   hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);

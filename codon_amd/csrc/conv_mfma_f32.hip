@@ -186,11 +186,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   // 55.35 -> 53.67 ms (94.3 % -> 97.3 % of the fp32 MFMA peak), config-2 forward 1 005 -> 980 ms; bit-identical results.
   // Lanes past the tile's last position are exec-masked (they would land in the next channel's plane); out-of-image
   // positions carry an out-of-range offset and land as zeros.  k = 1 (0.385 -> 0.392 ms) and the gated staging (needs
-  // the VALU) keep the register path.  -DCODON_F32_DMA=0 restores it everywhere (A/B).
-#ifndef CODON_F32_DMA
-#define CODON_F32_DMA 1
-#endif
-  constexpr bool DMA = (CODON_F32_DMA != 0) && !GATE && KS != 1;
+  // the VALU) keep the register path.
+  constexpr bool DMA = !GATE && KS != 1;
   typedef __attribute__((address_space(3))) void lds_void;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   float xg_[DMA ? 1 : CK][DMA ? 1 : PJ], xi_[GATE ? CK : 1][GATE ? PJ : 1], chs[GATE ? CK : 1];
@@ -522,9 +519,6 @@ static bool small_grid(const codon_conv_desc* d) {
 // dispatcher puts the workgroups of two concurrent 128-workgroup launches on the SAME CUs (rocprofv3 trace: both overlap in
 // time and each takes 345 us instead of 202).  A dynamic-LDS request that brings a workgroup above half of the CU's 160 KB
 // makes every workgroup the only one on its CU, so a concurrent launch must take the free CUs.  Bytes of padding for `kernel`.
-#ifndef CODON_SOLO_LDS
-#define CODON_SOLO_LDS 1
-#endif
 template <class K>
 static unsigned solo_lds_pad(K kernel) {
   // hipFuncSetAttribute acts on the CURRENT device's function object: one slot per (kernel instantiation, device), so
@@ -543,7 +537,7 @@ static unsigned solo_lds_pad(K kernel) {
   if (pad < 0) {
     int want = 0;
     hipFuncAttributes a;
-    if (CODON_SOLO_LDS && hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess) {
+    if (hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess) {
       want = 82 * 1024 - (int)a.sharedSizeBytes;
       if (want < 0) want = 0;
       if (want > 0 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
@@ -645,15 +639,12 @@ int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon
   }
 }
 
-#ifndef CODON_CHAIN_NW
-#define CODON_CHAIN_NW 4
-#endif
 // d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1
 int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* w_chain,
                           const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
-  constexpr int NWC = CODON_CHAIN_NW;
+  constexpr int NWC = 4;     // waves per workgroup (one 8-wave workgroup per CU on a 16x32 tile measured slower: DESIGN.md 3.1)
   const bool small = small_grid(d);
   const int TH = (small ? 1 : 2) * NWC;
   ConvParams p;
@@ -684,20 +675,15 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   return check_launch("conv_mfma_f32_kernel<fused 1x1>");
 }
 
-// pixel rows per wave of the plain 64-cout convs: 2 = 8 x 32 tile (4 operand fetches per 4 MFMAs), 4 = 16 x 32 tile (6 per 8)
-#ifndef CODON_F32_PSEG364
-#define CODON_F32_PSEG364 2
-#endif
-#ifndef CODON_F32_PSEG564
-#define CODON_F32_PSEG564 2
-#endif
+// pixel rows per wave: 2 = 8 x 32 tile (4 operand fetches per 4 MFMAs) everywhere; the 16 x 32 tile (6 per 8) was measured on the
+// 64-cout convs in rounds 2 and 4: no gain (profiles/HISTORY.md)
 int conv2d_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* res,
                    hipStream_t stream) {
   const int key = d->ksize * 1000000 + d->cin * 1000 + d->cout;
   switch (key) {
     case 5128128: return launch_conv<5, 128, 128, 2>(d, x, w, y, res, stream);
-    case 5064064: return launch_conv<5, 64, 64, CODON_F32_PSEG564>(d, x, w, y, res, stream);
-    case 3064064: return launch_conv<3, 64, 64, CODON_F32_PSEG364>(d, x, w, y, res, stream);
+    case 5064064: return launch_conv<5, 64, 64, 2>(d, x, w, y, res, stream);
+    case 3064064: return launch_conv<3, 64, 64, 2>(d, x, w, y, res, stream);
     case 3128064: return launch_conv<3, 128, 64, 2>(d, x, w, y, res, stream);
     case 3064128: return launch_conv<3, 64, 128, 2>(d, x, w, y, res, stream);  // dgrad of conv7
     case 1128064: return launch_conv<1, 128, 64, 2>(d, x, w, y, res, stream);

@@ -27,15 +27,9 @@ namespace codon {
 
 constexpr int WC8_TH = 4;
 constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
-#ifndef CODON_WC8_DMA3
-#define CODON_WC8_DMA3 1              // 0: k = 3 through the register path (A/B)
-#endif
-#ifndef CODON_WC8_CIT3
-#define CODON_WC8_CIT3 2
-#endif
 // k = 3: cin tiles per workgroup, each with its own 2*KS waves: 2 -> 64 cout x 64 cin, 12 waves = 3 per SIMD (balanced),
 // twice the MFMAs per staged byte and per barrier
-template <int KS> struct Wc8Cit { static constexpr int value = KS == 3 ? CODON_WC8_CIT3 : 1; };
+template <int KS> struct Wc8Cit { static constexpr int value = KS == 3 ? 2 : 1; };
 // k = 5: 2 x 5 (cout tile, filter row) waves would sit 3/3/2/2 on the four SIMDs (15 tap-MFMAs per k-step on the busy ones
 // against 12.5 on average).  The row waves therefore take taps dx = 0..3 only and two more waves (one per cout tile) take
 // the COLUMN dx = 4 of all five rows: 12 waves, 12/12/13/13 per SIMD (waves i, i+4, i+8 share a SIMD).
@@ -133,7 +127,7 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
   // a lane carries the global offset of its slot, border and pitch-padding slots are out of range and land as zeros.
   // Measured (same box, with the asm reads and the tile pipeline below): 5x5 128->128 6.76 -> 6.12 ms, 5x5 64->64 1.79 -> 1.61,
   // 3x3 64->64 0.845 -> 0.77; the 2-k-step tiles of k = 1 (0.69 -> 0.71 with DMA) keep the register path.
-  constexpr bool DMA = CODON_WC8_DMA3 ? !KSPLIT : (KS == 5);
+  constexpr bool DMA = !KSPLIT;
   constexpr int XPS = XPITCH / 16, GPS = GPITCH / 16;       // plane pitch in slots
   constexpr int XPIECES = (XPL * XPS + 63) / 64, GPIECES = (GPL * GPS + 63) / 64;
   constexpr int XBYTES = XPIECES * 1024, GBYTES = GPIECES * 1024;
@@ -146,11 +140,8 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
   // k = 5: THREE tile buffers -- the DMA of tile t+3 is issued behind tile t's MFMAs and has two tile times (not one) to
   // land; the wait in front of the publishing barrier leaves the youngest tile's pieces in flight (counted vmcnt: every
   // wave issues exactly PPW pieces per tile, loads return in order).  110 KB of LDS: the kernel runs one workgroup per
-  // CU anyway (12 waves).  -DCODON_WC8_NBUF5=2 restores the double buffer (A/B).
-#ifndef CODON_WC8_NBUF5
-#define CODON_WC8_NBUF5 3
-#endif
-  constexpr int NBUF = (DMA && KS == 5) ? CODON_WC8_NBUF5 : 2;
+  // CU anyway (12 waves).
+  constexpr int NBUF = (DMA && KS == 5) ? 3 : 2;
   static_assert(NBUF == 2 || (NBUF == 3 && NPIECE % NWV == 0 && PPW <= 15), "counted vmcnt needs the same piece count in every wave");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * (XBYTES + GBYTES)];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -612,10 +603,7 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
 int launch_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
                         hipStream_t stream);
 
-#ifndef CODON_WGRAD16_TARGET
-#define CODON_WGRAD16_TARGET 256
-#endif
-constexpr int WGRAD16_TARGET_BLOCKS = CODON_WGRAD16_TARGET;   // workgroups per launch the band split aims for
+constexpr int WGRAD16_TARGET_BLOCKS = 256;   // workgroups per launch the band split aims for: one per CU
 
 struct Wgrad16Plan {
   int nbands, nsplit, nchan_blocks;

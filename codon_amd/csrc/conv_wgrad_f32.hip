@@ -223,10 +223,7 @@ static bool wgrad_plan(const codon_conv_desc* d, WgradPlan* pl) {
   // misaligned, the round-1 kernel runs on the same band split
   pl->t16 = conv_wgrad_f32_t16_shape(d);
   const int plan_blocks = pl->t16 ? (co / 64) * (ci / (k == 1 ? 128 : 32)) : pl->nchan_blocks;
-#ifndef CODON_WGRAD32_TARGET
-#define CODON_WGRAD32_TARGET 256
-#endif
-  const int target = pl->t16 ? CODON_WGRAD32_TARGET : 1024;       // workgroups per launch: 1 per CU (A/B: 256 beats 512 / 768 by 2-4 % on the 64-channel convs) / 2 x 2 per CU
+  const int target = pl->t16 ? 256 : 1024;       // workgroups per launch: 1 per CU (A/B: 256 beats 512 / 768 by 2-4 % on the 64-channel convs) / 2 x 2 per CU
   const int tiles_y = (d->height + 3) / 4;
   // enough workgroups to fill the chip, but bounded workspace: bands per image
   int want = (target + plan_blocks * d->batch - 1) / (plan_blocks * d->batch);

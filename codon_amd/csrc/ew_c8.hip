@@ -258,14 +258,12 @@ constexpr int W1C8_ROWS = 8;
 // One wave per 8-channel plane (8 waves): 72 accumulators per lane instead of 144 -- 4 instead of 2 waves per SIMD keep
 // twice the loads in flight (the kernel waits on memory: 61 % of its wave cycles parked, 2.7 TB/s with two planes per
 // wave).  Every accumulator still sees its pixels in the same order: bit-identical to the two-plane form.
-#ifndef CODON_W1C8_PLANES
-#define CODON_W1C8_PLANES 1          // planes per wave: 1 (8 waves) or 2 (4 waves, A/B)
-#endif
+constexpr int W1C8_PLANES = 1;       // planes per wave: 1 (8 waves); 2 (4 waves, 208 VGPRs) measured slower in round 4
 template <class E>
-__global__ __launch_bounds__(512 / CODON_W1C8_PLANES) void conv1ch_wgrad_c8_kernel(C8Slice a, const float* __restrict__ s,
+__global__ __launch_bounds__(512 / W1C8_PLANES) void conv1ch_wgrad_c8_kernel(C8Slice a, const float* __restrict__ s,
                                                                                   float* __restrict__ part, int H, int W,
                                                                                   int nrowblk) {
-  constexpr int NP = CODON_W1C8_PLANES;
+  constexpr int NP = W1C8_PLANES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / nrowblk, rb = blockIdx.x % nrowblk;
@@ -336,10 +334,10 @@ int conv1ch_wgrad_c8(int B, int H, int W, const void* a, int a_ctotal, int a_cof
   const int nrowblk = (H + W1C8_ROWS - 1) / W1C8_ROWS;
   const C8Slice as = c8_mk(a, a_ctotal, a_coff, HW);
   if (dtype == CODON_F16)
-    hipLaunchKernelGGL(conv1ch_wgrad_c8_kernel<C8F16>, dim3(B * nrowblk), dim3(512 / CODON_W1C8_PLANES), 0, stream, as, s, ws, H,
+    hipLaunchKernelGGL(conv1ch_wgrad_c8_kernel<C8F16>, dim3(B * nrowblk), dim3(512 / W1C8_PLANES), 0, stream, as, s, ws, H,
                        W, nrowblk);
   else
-    hipLaunchKernelGGL(conv1ch_wgrad_c8_kernel<C8Bf16>, dim3(B * nrowblk), dim3(512 / CODON_W1C8_PLANES), 0, stream, as, s, ws, H,
+    hipLaunchKernelGGL(conv1ch_wgrad_c8_kernel<C8Bf16>, dim3(B * nrowblk), dim3(512 / W1C8_PLANES), 0, stream, as, s, ws, H,
                        W, nrowblk);
   const int st = check_launch("conv1ch_wgrad_c8_kernel");
   if (st != CODON_OK) return st;
@@ -737,10 +735,7 @@ __global__ __launch_bounds__(256, 2) void cac_bwd_reduce_acc_c8_kernel(
     C8Slice g_out, C8Slice g_outc, C8Slice pre, C8Slice pre_c, C8Slice g_in, C8Slice g_in_c, const float* __restrict__ ch,
     const float* __restrict__ sp, const float* __restrict__ pools, const float* __restrict__ pooled, float* __restrict__ g_z,
     float* __restrict__ part_gch, int* __restrict__ part_arg, int* __restrict__ argch, long HW, int ntiles, int accumulate_in) {
-#ifndef CODON_CAC_ACC_KH
-#define CODON_CAC_ACC_KH 4
-#endif
-  constexpr int KH = CODON_CAC_ACC_KH;                // pixels in flight per thread
+  constexpr int KH = 4;                               // pixels in flight per thread (8 needed 351 VGPRs)
   __shared__ float red_s[64][4];
   __shared__ int red_a[128][4];
   __shared__ float st_sp[EW_NP][256], st_gsp[EW_NP][256], st_pmx[EW_NP][256];

@@ -22,7 +22,7 @@ class GradSync:
     """direct=True (default): `loss.backward()` through CODONNet ADDS the 44 parameter gradients into the .grad views of the
     flat buffer inside the backward's own kernels (codon_amd.autograd._grad_sink) -- no per-tensor AccumulateGrad add.  What
     that changes for the caller: `torch.autograd.grad(loss, params)` on such a model returns None for these parameters (use
-    .backward(), or direct=False), and post-accumulate-grad hooks on them do not fire.  Anything that breaks the aliasing
+    .backward(), or direct=False); post-accumulate-grad hooks still fire.  Anything that breaks the aliasing
     (optimizer.zero_grad() with set_to_none=True, a foreign .grad) silently falls back to the ordinary route for that step."""
 
     def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, direct: bool = True):

@@ -118,6 +118,42 @@ def test_bench_four_ranks_strong_scaling_and_diagnostics():
         assert r["train_step_ms"]["min_ms"] <= r["train_step_ms"]["median_ms"]
 
 
+HW_KEYS = {"power_w_p50", "power_w_p95", "sclk_mhz_p50", "power_cap_w", "hwmon_samples", "hwmon_matched_by"}
+
+
+@pytest.mark.gpu
+def test_bench_six_ranks_weak_scaling_rehearsal_of_the_eight_gpu_line():
+    """The driver's N = 8 line (`bench.py --gpus 8 --steps K --warmup W`: weak scaling, the self-check, both legs) rehearsed
+    with as many ranks as this pool lets share one card: SIX (the box's process guard kills a run with more than six
+    processes on the GPU, so the N = 8 case itself cannot be started here; the code path does not depend on N).  Every
+    rank's record carries its socket power and shader clock over the timed regions (hwmon), so that a node-level power
+    budget on the 8-GPU node reads as eight lower clocks in SCALE_rNN.json rather than as an unexplained efficiency loss."""
+    d = _run(["--gpus", "6", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "48",
+              "--width", "64"], timeout=900)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 6 and d["rccl_ranks"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["batch_per_gpu"] == 1 and d["config"]["global_batch"] == 6
+    assert abs(d["value"] - 6 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
+    assert [r["rank"] for r in d["ranks"]] == list(range(6))
+    assert d["grad_equal"] is True and d["rccl_selfcheck"]["ranks"] == 6, d.get("rccl_selfcheck")
+    fb = d["fwd_bwd"]
+    assert fb["rccl_ranks"] == 6 and fb["global_batch"] == 6 and fb["scaling"] == "weak" and fb["allreduce_us"] > 0
+    for r in d["ranks"]:
+        assert HW_KEYS <= set(r) and "train_power_w_p50" in r and "train_sclk_mhz_p50" in r, r
+        assert r["fwd_step_ms"]["min_ms"] <= r["fwd_step_ms"]["median_ms"] and r["train_step_ms"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_carries_power_and_clock_and_the_profile_hash():
+    d = _run(["--steps", "3", "--warmup", "1", "--batch", "4", "--height", "96", "--width", "128", "--no-cpu-baseline"])
+    r0 = d["ranks"][0]
+    assert HW_KEYS <= set(r0) and "train_power_w_p50" in r0
+    if r0["hwmon_samples"]:                  # sysfs visible on this box: plausible numbers for an MI355X under load
+        assert 50 < r0["power_w_p50"] < 1600 and 300 < r0["sclk_mhz_p50"] < 3000, r0
+    rf = d["roofline"]
+    assert "traffic_from_hash" in rf and len(rf["lib_source_hash"]) == 32
+    assert "traffic_from_hash" in d["fwd_bwd"]["roofline"]
+
+
 @pytest.mark.gpu
 def test_bench_retries_a_taken_rendezvous_port_and_times_out(capfd):
     """self_launch: a port that is taken between bind-and-close and the children's bind is retried on another one; a

@@ -509,8 +509,9 @@ def test_training_schedules_agree_bit_for_bit():
         assert torch.equal(res[0][1][n], g6[n]), n
     # ... dL/d(fuse) collected by the trunk's input-gradient convs (round 5) or by ew_sum_mask: NOT the same roundings -- the
     # running sum is stored in bf16 after each term (as the reference's own bf16 autograd accumulates, and as dL/d(inputs)
-    # does above), the pass rounded the fp32 sum of four terms once -- so everything downstream of dL/d(fuse) agrees to bf16
-    # rounding noise, everything upstream (the trunk, conv11, output) bit for bit
+    # does above), the pass rounded the fp32 sum of four terms once, and the trunk's two input-gradient convs swap places (the
+    # conv5x5 runs last and carries the add) -- so everything from the trunk's second iteration on agrees to bf16 rounding
+    # noise, what precedes it in the backward (conv11, output) bit for bit
     oldg = A.SUM_GFUSE_IN_DGRAD
     try:
         A.SUM_GFUSE_IN_DGRAD = not oldg
@@ -521,11 +522,14 @@ def test_training_schedules_agree_bit_for_bit():
     finally:
         A.SUM_GFUSE_IN_DGRAD = oldg
     for n in res[0][1]:
-        if n.split(".")[0] in ("conv8", "conv9", "conv10", "confuse_fuse", "conv11", "output"):
+        if n.split(".")[0] in ("conv11", "output"):
             assert torch.equal(res[0][1][n], g7[n]), n
         else:
             a, b_ = res[0][1][n].double(), g7[n].double()
-            assert float((a - b_).norm() / b_.norm()) < 2e-2, (n, float((a - b_).norm() / b_.norm()))
+            # (the gate tensors carry less than two digits in bf16 whoever computes them: cancellation; they are
+            # held to the reference's own bf16 autograd by test_bf16_gradients_vs_reference_bf16_autograd)
+            tol = 0.15 if n.startswith("attention") else 2e-2
+            assert float((a - b_).norm() / b_.norm()) < tol, (n, float((a - b_).norm() / b_.norm()))
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -92,7 +92,7 @@ def test_deferred_reduce_equals_the_immediate_form_bit_for_bit(dtype):
 @pytest.mark.parametrize("defer", [True, False])
 def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype, defer):
     """GradSync(direct=True): the backward kernels add into the .grad views themselves.  Same values as the ordinary
-    route bit for bit (0 + g == g), a second backward accumulates (g + g), nothing goes through AccumulateGrad, and a
+    route bit for bit (0 + g == g), a second backward accumulates (g + g), and a
     dropped view (zero_grad(set_to_none=True)) falls back to the ordinary route for that step."""
     from codon_amd import autograd
     from codon_amd.dist import GradSync
@@ -114,15 +114,18 @@ def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype
         gs.zero_grad()
         (m(x, y) - tgt).abs().mean().backward()
         torch.cuda.synchronize()
-        assert not calls                       # AccumulateGrad never ran for the 44 parameters
+        assert len(calls) == 44                # post-accumulate hooks still fire (AccumulateGrad sees "no gradient": no add)
         names = [n for n, _ in gs.named]
         assert len(names) == 44
         bad = [n for n, p in gs.named if not torch.equal(p.grad, ref[n])]
         assert not bad, bad
         assert all(p.grad._base is gs.flat for p in gs.params)
-        (m(x, y) - tgt).abs().mean().backward()                 # accumulates: g + g
-        bad = [n for n, p in gs.named if not torch.equal(p.grad, ref[n] + ref[n])]
+        # a second backward accumulates: ((g + r_1) + r_2) + ... over the uses of a shared weight -- g + g up to fp32
+        # re-association (exactly g + g for the single-use tensors)
+        (m(x, y) - tgt).abs().mean().backward()
+        bad = [n for n, p in gs.named if rel_rmse(p.grad.cpu(), (ref[n] + ref[n]).cpu()) > 1e-6]
         assert not bad, bad
+        assert torch.equal(m.conv7.weight.grad, ref["conv7.weight"] + ref["conv7.weight"])
         # the unused tensors stay without gradient
         assert m.attention_c5.mlp[1].weight.grad is None
         # fallback: one view dropped -> the whole step goes through autograd's accumulation, then the views are re-adopted

@@ -176,6 +176,15 @@ def main():
                      "time-weighted; dispatches outside 0.5-3 GHz or busy > 1 rejected.  Profiled passes clock lower than "
                      "un-profiled runs: compare ratios, not milliseconds.",
            "kernels": dict(sorted(ks.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))}
+    # which build of the kernels these counters belong to: bench.py prints it beside roofline.traffic (`traffic_from_hash`),
+    # so a ratio measured before a later kernel change is visible from the line
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from codon_amd import _lib
+        doc["lib_source_hash"] = _lib.build_info()["source_hash_built"]
+    except Exception as e:           # noqa: BLE001
+        doc["lib_source_hash"] = None
+        print(f"pmc_report: library source hash unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     json.dump(doc, open(out, "w"), indent=1)
     print(f"{'kernel':72s} {'n':>4s} {'ms':>7s} {'GB':>7s} {'x alg':>6s} {'GHz':>5s} {'busy':>5s}")
     for k, v in list(doc["kernels"].items())[:20]:
