@@ -69,6 +69,7 @@ SIGNATURES = {
     "codon_cac_fused_tiles": (_I, [_I, _I]),
     "codon_cac_fused_finish": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "codon_cac_gate_folded_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "codon_cac_tail_fwd": (C.c_int, [_I, _I, _I, _I] + [_P] * 14 + [_P]),
     "codon_conv2d_gated_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _TP, _P, _P, _P, _P, _P]),
     "codon_conv2d_gated_emit_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _TP, _P, _P, _P, _P, _TP, _P]),
     "codon_conv_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),

@@ -296,6 +296,157 @@ int cac_fused_finish(int B, int H, int W, int ntiles, const float* partials, con
   return check_launch("cac_pool_combine_kernel");
 }
 
+// ---- the whole CAC gate of a block in ONE launch (round 5) ---------------------------------------------------------------
+// At one image per call (the reference script's own calling pattern, /root/reference/CODON_X4/test.py:116-125) the gate of a
+// block was four dependent launches of a few microseconds each -- fold, combine, pool finish + MLP, spatial conv -- i.e. 20
+// launches per forward that cost more in dependency gaps than in work.  Here one grid does all of it:
+//   workgroups [0, nsp)          : a 32 x 32 tile of sp = sigmoid(conv5x5_{2->1}(pooled)) (CAC_module.py:88,92-93), the pooled
+//                                  planes formed while the halo tile is staged (pool_c != null: { max(max_c, max_d),
+//                                  (sum_c + sum_d) / 128 } from the two per-stream maps, CAC_module.py:81) and, when
+//                                  `pooled_out` is given (training keeps it), written for the tile's own pixels;
+//   workgroups [nsp, nsp + F B)  : fold f of image b over the per-tile {sum, max} rows (cac_fold_kernel's ranges); the LAST
+//                                  fold of an image to arrive (one atomic per workgroup, as wsum.hip) finishes the pools over
+//                                  the F folded rows and runs the MLP + sigmoid (cac_gate_kernel's arithmetic and order).
+// Every sum keeps the order of the four-launch form: same bits (tests/test_gpu_c8.py).  counters: B int32, zero on entry,
+// left at zero.
+struct CacTailArgs {
+  const float* partials; const float* pool_c; const float* pool_d; const float* pooled_in; float* pooled_out;
+  float* folded; int* counters;
+  const float* w1; const float* b1; const float* w2; const float* b2; const float* ws;
+  float* ch; float* pools_out; float* sp;
+  int H, W, tiles_x, tiles_y, nsp, ntiles, per;
+  float inv_hw;
+};
+
+__global__ __launch_bounds__(256) void cac_tail_kernel(const CacTailArgs a) {
+  __shared__ float tl[2][SPF_HALO][SPF_PITCH];
+  __shared__ bool last;
+  const int tid = threadIdx.x;
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  if ((int)blockIdx.x < a.nsp) {
+    const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
+    const int x0 = tx * SPF_T, y0 = ty * SPF_T;
+    const long ib = (long)b * 2 * HW;
+    for (int e = tid; e < 2 * SPF_HALO * SPF_HALO; e += 256) {
+      const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
+      const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
+      const int yy = y0 + r - 2, xx = x0 + q - 2;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const long o = ib + c * HW + (long)yy * W + xx;
+        if (a.pool_c) {
+          v = c == 0 ? fmaxf(a.pool_c[o], a.pool_d[o]) : (a.pool_c[o] + a.pool_d[o]) * (1.f / 128.f);
+          if (a.pooled_out && r >= 2 && r < 2 + SPF_T && q >= 2 && q < 2 + SPF_T) a.pooled_out[o] = v;
+        } else {
+          v = a.pooled_in[o];
+        }
+      }
+      tl[c][r][q] = v;
+    }
+    __syncthreads();
+    const int cx = tid & 31, r0 = (tid >> 5) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float win[8][5];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) win[rr][dx] = tl[c][r0 + rr][cx + dx];
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const float k = a.ws[(c * 5 + dy) * 5 + dx];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fmaf(k, win[i + dy][dx], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = y0 + r0 + i, gx = x0 + cx;
+      if (gy < H && gx < W) a.sp[(long)b * HW + (long)gy * W + gx] = 1.f / (1.f + expf(-acc[i]));
+    }
+    return;
+  }
+  // fold f of image b, then -- last arrival only -- the pool finish + MLP
+  const int fb = (int)blockIdx.x - a.nsp;
+  const int f = fb % CODON_CAC_FOLDS, b = fb / CODON_CAC_FOLDS;
+  float2* const folded = reinterpret_cast<float2*>(a.folded) + (long)b * CODON_CAC_FOLDS * 128;
+  if (tid < 128) {
+    const int t0 = f * a.per, t1 = min(t0 + a.per, a.ntiles);
+    float s = 0.f, m = -INFINITY;
+    const float2* p = reinterpret_cast<const float2*>(a.partials) + (long)b * a.ntiles * 128 + tid;
+    for (int t = t0; t < t1; ++t) {
+      const float2 v = p[(long)t * 128];
+      s += v.x;
+      m = fmaxf(m, v.y);
+    }
+    folded[f * 128 + tid] = make_float2(s, m);
+  }
+  __threadfence();                 // this workgroup's row is visible device-wide before its arrival is
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(&a.counters[b], 1) == CODON_CAC_FOLDS - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();                 // acquire: the other workgroups' rows
+  float* const pool = &tl[0][0][0];          // [2][128]
+  float* const hid = pool + 256;             // [2][8]
+  if (tid == 0) a.counters[b] = 0;           // ready for the next block's launch on this buffer
+  if (tid < 128) {
+    float s = 0.f, m = -INFINITY;
+    for (int t = 0; t < CODON_CAC_FOLDS; ++t) {
+      // (atomic loads: never served from a stale line of this XCD's cache)
+      const unsigned* q = reinterpret_cast<const unsigned*>(a.folded) + (((long)b * CODON_CAC_FOLDS + t) * 128 + tid) * 2;
+      s += __uint_as_float(__atomic_load_n(q, __ATOMIC_RELAXED));
+      m = fmaxf(m, __uint_as_float(__atomic_load_n(q + 1, __ATOMIC_RELAXED)));
+    }
+    pool[tid] = s * a.inv_hw;
+    pool[128 + tid] = m;
+    if (a.pools_out) {
+      a.pools_out[((long)b * 2 + 0) * 128 + tid] = s * a.inv_hw;
+      a.pools_out[((long)b * 2 + 1) * 128 + tid] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {  // hidden layer: Linear(128, 8) + ReLU, for avg (tid < 8) and max
+    const int which = tid >> 3, j = tid & 7;
+    float v = a.b1[j];
+    for (int k = 0; k < 128; ++k) v = fmaf(a.w1[j * 128 + k], pool[which * 128 + k], v);
+    hid[which * 8 + j] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  if (tid < 64) {  // Linear(8, 64) for both pools, summed, sigmoid
+    float a0 = a.b2[tid], a1 = a.b2[tid];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 = fmaf(a.w2[tid * 8 + j], hid[j], a0);
+      a1 = fmaf(a.w2[tid * 8 + j], hid[8 + j], a1);
+    }
+    const float z = a0 + a1;
+    a.ch[(long)b * 64 + tid] = 1.f / (1.f + expf(-z));
+  }
+}
+
+int cac_tail_fwd(int B, int H, int W, int ntiles, const float* partials, const float* pool_c, const float* pool_d,
+                 const float* pooled_in, float* pooled_out, float* folded, int* counters, const float* w1, const float* b1,
+                 const float* w2, const float* b2, const float* ws, float* ch, float* pools_out, float* sp, hipStream_t stream) {
+  CacTailArgs a;
+  a.partials = partials; a.pool_c = pool_c; a.pool_d = pool_d; a.pooled_in = pooled_in; a.pooled_out = pooled_out;
+  a.folded = folded; a.counters = counters; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ws = ws;
+  a.ch = ch; a.pools_out = pools_out; a.sp = sp;
+  a.H = H; a.W = W;
+  a.tiles_x = (W + SPF_T - 1) / SPF_T; a.tiles_y = (H + SPF_T - 1) / SPF_T;
+  const long nsp = (long)B * a.tiles_x * a.tiles_y, nblk = nsp + (long)B * CODON_CAC_FOLDS;
+  CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "cac_tail_fwd: grid too large");
+  a.nsp = (int)nsp; a.ntiles = ntiles;
+  a.per = (ntiles + CODON_CAC_FOLDS - 1) / CODON_CAC_FOLDS;
+  a.inv_hw = (float)(1.0 / ((double)H * W));
+  hipLaunchKernelGGL(cac_tail_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, a);
+  return check_launch("cac_tail_kernel");
+}
+
 int cac_spatial_fwd(int B, int H, int W, const float* pooled, const float* w, float* sp, hipStream_t stream) {
   const int tiles_x = (W + SPF_T - 1) / SPF_T, tiles_y = (H + SPF_T - 1) / SPF_T;
   const long blocks = (long)B * tiles_x * tiles_y;

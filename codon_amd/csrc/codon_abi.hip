@@ -55,6 +55,8 @@ int cac_bwd_reduce_acc(int, int, int, const codon_tensor*, const codon_tensor*, 
                        const float*, const float*, const float*, const float*, float*, float*, int*, int*, const codon_tensor*,
                        const codon_tensor*, int, int, hipStream_t);
 int cac_fused_tiles(int, int);
+int cac_tail_fwd(int, int, int, int, const float*, const float*, const float*, const float*, float*, float*, int*, const float*,
+                 const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
                    hipStream_t);
@@ -275,6 +277,21 @@ int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const f
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_fused_finish: bad shape");
   return cac_fused_finish(batch, height, width, cac_fused_tiles(height, width), partials, pool_c, pool_d, folded, pooled,
                           (hipStream_t)stream);
+}
+
+int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t ntiles, const float* partials,
+                       const float* pool_c, const float* pool_d, float* pooled, float* folded, int32_t* counters,
+                       const float* w1, const float* b1, const float* w2, const float* b2, const float* w_spatial, float* ch,
+                       float* pools_out, float* sp, codon_stream_t stream) {
+  CODON_REQUIRE(partials && folded && counters && w1 && b1 && w2 && b2 && w_spatial && ch && sp, CODON_ERR_BAD_ARG,
+                "cac_tail_fwd: null pointer");
+  CODON_REQUIRE((pool_c != nullptr) == (pool_d != nullptr) && (pool_c || pooled), CODON_ERR_BAD_ARG,
+                "cac_tail_fwd: pool_c and pool_d together, or pooled to read");
+  CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_tail_fwd: bad shape");
+  CODON_REQUIRE(ntiles == (pool_c ? cac_fused_tiles(height, width) : cac_stats_tiles(height, width)), CODON_ERR_BAD_ARG,
+                "cac_tail_fwd: ntiles %d does not match the producer of the partials", ntiles);
+  return cac_tail_fwd(batch, height, width, ntiles, partials, pool_c, pool_d, pool_c ? nullptr : pooled, pool_c ? pooled : nullptr,
+                      folded, counters, w1, b1, w2, b2, w_spatial, ch, pools_out, sp, (hipStream_t)stream);
 }
 
 int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, const float* folded, const float* w1,

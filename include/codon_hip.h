@@ -147,6 +147,19 @@ int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const f
 int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, const float* folded, const float* w1,
                               const float* b1, const float* w2, const float* b2, float* ch, float* pools_out,
                               codon_stream_t stream);
+/* The whole gate of a block in ONE launch (replaces codon_cac_fused_finish + codon_cac_gate_folded_fwd + codon_cac_spatial_fwd,
+ * or codon_cac_gate_fwd + codon_cac_spatial_fwd behind codon_cac_stats_fwd): at one image per call -- the reference script's
+ * own calling pattern, /root/reference/CODON_X4/test.py:116-125 -- these were 20 dependent few-microsecond launches per
+ * forward.  partials: (B, ntiles, 128, 2) per-tile { sum, max }; ntiles = codon_cac_fused_tiles (pool_c / pool_d given: the
+ * two per-stream maps of codon_conv_chain1x1_stats_fwd, combined on the fly; pooled (B,2,H,W) is WRITTEN when non-null) or
+ * codon_cac_stats_tiles (pool_c = pool_d = NULL: pooled is READ, as codon_cac_stats_fwd left it).  folded: (B,
+ * CODON_CAC_FOLDS, 128, 2) scratch; counters: B int32, zero on entry and on exit.  Outputs as the calls it replaces: ch
+ * (B,64), sp (B,1,H,W), pools_out (B,2,128) or NULL.  16-bit path: bit for bit the results of the three calls; fp32 path:
+ * the pools are folded before they are finished (codon_cac_gate_fwd adds the tiles serially), identical for <= CODON_CAC_FOLDS tiles. */
+int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t ntiles, const float* partials,
+                       const float* pool_c, const float* pool_d, float* pooled, float* folded, int32_t* counters,
+                       const float* w1, const float* b1, const float* w2, const float* b2, const float* w_spatial, float* ch,
+                       float* pools_out, float* sp, codon_stream_t stream);
 
 /* A conv whose input is the CAC gate-apply of the producing block, formed while the input tile is staged instead of
  * being written to HBM and read back (inference):   x = pre * (ch * sp) + inputs ,  y = conv(x) [ReLU]
