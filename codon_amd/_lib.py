@@ -46,6 +46,14 @@ WGRAD_DEFER = 2                                     # CODON_WGRAD_DEFER
 W1_FLIP, W1_ACCUMULATE, W1_DEFER = 1, 2, 4          # CODON_W1_*
 
 
+CAST_MAX = 32                                       # CODON_CAST_MAX
+
+
+class CastDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("src", C.c_void_p * CAST_MAX), ("count", C.c_int64 * CAST_MAX),
+                ("dtype", C.c_int32 * CAST_MAX)]
+
+
 class ReduceItem(C.Structure):
     _fields_ = [("out", C.c_void_p), ("part", C.c_void_p * REDUCE_MAX_USES), ("stride", C.c_int64), ("nuse", C.c_int32),
                 ("nparts", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32), ("taps", C.c_int32), ("nchunk", C.c_int32),
@@ -106,6 +114,9 @@ SIGNATURES = {
     "codon_ew_sum_mask": (C.c_int, [_I, _I, _I, _I, _TP, _I, _TP, _TP, _TP, _TP, _TP, _I, _P]),
     "codon_conv1x1_bwd_gated": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _TP, _P, _P, _S, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "codon_cac_bwd_reduce_acc": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _P, _P, _TP, _TP, _I, _I, _P]),
+    "codon_conv_pair_begin": (C.c_int, []),
+    "codon_conv_pair_end": (C.c_int, [_P]),
+    "codon_cast_multi": (C.c_int, [C.POINTER(CastDesc), _P, _P]),
     "codon_reduce_multi": (C.c_int, [C.POINTER(ReduceItem), _I, _P]),
     "codon_weight_checksum_workspace_bytes": (_S, []),
     "codon_weight_checksum": (C.c_int, [C.POINTER(WsumDesc), _P, _P, _I, _P, _P]),

@@ -106,6 +106,9 @@ int l1_fwd(long, const float*, const float*, float*, int, double*, hipStream_t);
 int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*, float*, float, float, hipStream_t);
 
 int reduce_multi(const codon_reduce_item*, int, hipStream_t);
+int cast_multi(const codon_cast_desc*, float*, hipStream_t);
+int conv_pair_begin_16();
+int conv_pair_end_16(hipStream_t);
 size_t weight_checksum_workspace_bytes();
 int weight_checksum(const codon_wsum_desc*, void*, unsigned long long*, int, int*, hipStream_t);
 
@@ -505,6 +508,15 @@ int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codo
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "conv1ch_wgrad: bad shape");
   return conv1ch_wgrad(batch, height, width, a->data, a->ctotal, a->coff, s, dw, flip, (float*)workspace,
                        workspace_bytes, dtype, (hipStream_t)stream);
+}
+
+int codon_conv_pair_begin(void) { return conv_pair_begin_16(); }
+
+int codon_conv_pair_end(codon_stream_t stream) { return conv_pair_end_16((hipStream_t)stream); }
+
+int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream) {
+  CODON_REQUIRE(desc && dst, CODON_ERR_BAD_ARG, "cast_multi: null pointer");
+  return cast_multi(desc, dst, (hipStream_t)stream);
 }
 
 int codon_reduce_multi(const codon_reduce_item* items, int32_t n_items, codon_stream_t stream) {

@@ -88,9 +88,12 @@ template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = 4; };
 // RESW (with PERSIST): the WHOLE packed filter stays resident in LDS for the workgroup's lifetime -- loaded once, never
 // re-staged (a one-tile conv3x3 64->64 workgroup stages 72 KB of weights for 43 KB of input and 32 KB of output); the only
 // per-chunk traffic left is the halo tile, and the only barrier the one that publishes it (per chunk, not per stage).
+// The body takes its parameter block by reference and the (XCD-remapped) tile it starts on as an argument, so that the
+// same code serves the one-conv launch and the PAIR launch (conv_c8_pair_kernel below: two convs of one shape, e.g. the
+// depth and the colour stream of a block, as one grid).
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
           bool RESW = false>
-__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(const ConvC8Params p) {
+__device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int tile0) {
   static_assert(!PERSIST || (!FUSE && !GATE && C8_DMA), "the tile loop exists for the plain LDS-DMA convs");
   static_assert(!RESW || PERSIST, "a resident filter pays only over many tiles");
   typedef typename E::vec8 vec8;
@@ -127,14 +130,9 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(cons
   // moment the resident workgroups work on ~gridDim.x CONSECUTIVE tiles, as a one-tile-per-workgroup launch does, so
   // neighbouring tiles still meet in an XCD's L2 (a contiguous range per workgroup was measured first: 0.96 vs 0.82 ms,
   // every halo re-read came from HBM)
-  int t_cur, t_step;
-  if constexpr (PERSIST) {
-    t_cur = (int)xcd_remap(blockIdx.x, gridDim.x);
-    t_step = (int)gridDim.x;
-  } else {
-    t_cur = (int)xcd_remap(blockIdx.x, (unsigned)p.nblk);
-    t_step = p.nblk;
-  }
+  int t_cur = tile0, t_step;
+  if constexpr (PERSIST) t_step = (int)gridDim.x;
+  else t_step = p.nblk;
   int tx, ty, b;
   auto decode = [&](int tile, int& tx_, int& ty_, int& b_) {
     unsigned bid = (unsigned)tile;
@@ -671,6 +669,29 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(cons
   }   // tiles
 }
 
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
+          bool RESW = false>
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(const ConvC8Params p) {
+  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, PERSIST, RESW>(p, (int)xcd_remap(blockIdx.x, PERSIST ? gridDim.x : (unsigned)p.nblk));
+}
+
+// Two convs of ONE shape and kernel variant as one grid of 2 * nblk workgroups (round 5).  The depth and the colour stream of
+// a block are independent up to the CAC gate (/root/reference/CODON_X4/CODON_x4.py:75-84: conv2 | conv4, conv1 | conv5,
+// conv3 + confuse | conv6 + confuse_c); at one image per call each of their launches fills the chip 1.4 times (370 x 463:
+// 705 tiles on 512 slots), i.e. runs two rounds, the second a third full.  Two HIP streams overlapped them only as far as the
+// fork / join events let them (12 + 18 us per block, profiles/r05_b1_*_timeline.txt); one grid has no seam.  Each workgroup
+// picks its parameter block by its (XCD-remapped) index: same code, same order of operations per tile, same bits.
+struct ConvC8Pair {
+  ConvC8Params a, b;
+};
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
+__global__ __launch_bounds__(64 * NW, 2) void conv_c8_pair_kernel(const ConvC8Pair pp) {
+  const int nblk = pp.a.nblk;                                       // == pp.b.nblk (checked on the host)
+  const int v = (int)xcd_remap(blockIdx.x, 2u * (unsigned)nblk);
+  const bool second = v >= nblk;                                    // workgroup-uniform
+  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, false, false>(second ? pp.b : pp.a, second ? v - nblk : v);
+}
+
 // ---- 1x1 convolution (stand-alone confuse* and their dgrad): HBM-bound ---------------------------------------------
 // Y[co][pix] = sum_ci W[co][ci] X[ci][pix]: a plain GEMM over the flattened pixels of one image, no halo, no LDS.  A
 // wave owns 64 consecutive pixels (two 32-pixel MFMA column tiles) and all COUT rows.  B fragment of lane (pixel,
@@ -914,6 +935,60 @@ static int c8_resident_blocks(K kernel, int threads) {
 // path wants many short workgroups).  (The tile loop with STAGED weights, for the plain 3x3 and 5x5 64->64 convs, was
 // measured as a loss and is gone: tools/probes/conv_c8_persist_staged_experiment.patch, profiles/HISTORY.md.)
 constexpr int C8_RESIDENT_MIN_TILES = 8;
+// codon_pair_begin / codon_pair_end (per host thread): conv launches of the staged one-tile-per-workgroup kernels issued in
+// between are held back here and leave as a pair
+struct PairRecorder {
+  struct Call {
+    ConvC8Params p;
+    int (*single)(const ConvC8Params&, hipStream_t);
+    int (*pair)(const ConvC8Params&, const ConvC8Params&, hipStream_t);
+  };
+  bool active = false;
+  int n = 0;
+  Call call[2];
+};
+static thread_local PairRecorder g_pair;
+static PairRecorder* pair_recorder() { return g_pair.active ? &g_pair : nullptr; }
+
+template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
+static int launch_single_c8(const ConvC8Params& p, hipStream_t stream) {
+  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)p.nblk), dim3(64 * NW), 0, stream, p);
+  return check_launch("conv_c8_kernel");
+}
+template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
+static int launch_pair_c8(const ConvC8Params& a, const ConvC8Params& b, hipStream_t stream) {
+  ConvC8Pair pp;
+  pp.a = a; pp.b = b;
+  hipLaunchKernelGGL((conv_c8_pair_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3(2u * (unsigned)a.nblk), dim3(64 * NW), 0,
+                     stream, pp);
+  return check_launch("conv_c8_pair_kernel");
+}
+
+int conv_pair_begin_16() {
+  CODON_REQUIRE(!g_pair.active, CODON_ERR_BAD_ARG, "pair_begin: already inside a pair on this thread");
+  g_pair.active = true;
+  g_pair.n = 0;
+  return CODON_OK;
+}
+// returns the number of launches issued (0, 1 or 2) or a negative status
+int conv_pair_end_16(hipStream_t stream) {
+  CODON_REQUIRE(g_pair.active, CODON_ERR_BAD_ARG, "pair_end without pair_begin on this thread");
+  g_pair.active = false;
+  const int n = g_pair.n;
+  g_pair.n = 0;
+  if (n == 2 && g_pair.call[0].pair == g_pair.call[1].pair && g_pair.call[0].p.nblk == g_pair.call[1].p.nblk &&
+      g_pair.call[0].p.tiles_x == g_pair.call[1].p.tiles_x && g_pair.call[0].p.tiles_y == g_pair.call[1].p.tiles_y &&
+      (long)g_pair.call[0].p.nblk * 2 < (1L << 31)) {
+    const int st = g_pair.call[0].pair(g_pair.call[0].p, g_pair.call[1].p, stream);
+    return st == CODON_OK ? 1 : st;
+  }
+  for (int k = 0; k < n; ++k) {
+    const int st = g_pair.call[k].single(g_pair.call[k].p, stream);
+    if (st != CODON_OK) return st;
+  }
+  return n;
+}
+
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
@@ -939,8 +1014,18 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
       return check_launch("conv_c8_kernel<resident>");
     }
   }
-  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)nblk), dim3(64 * NW), 0, stream, p);
-  return check_launch("conv_c8_kernel");
+  if (PairRecorder* r = pair_recorder()) {
+    // inside codon_pair_begin / codon_pair_end: hold the launch back; pair_end issues two held launches of the same
+    // kernel variant on the same grid as ONE, anything else one by one in the order they came
+    if (r->n < 2) {
+      PairRecorder::Call& c = r->call[r->n++];
+      c.p = p;
+      c.single = &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>;
+      c.pair = &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>;
+      return CODON_OK;
+    }
+  }
+  return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>(p, stream);
 }
 
 template <class E>

@@ -34,6 +34,16 @@ GATED_EMIT = _os.environ.get("CODON_GATED_EMIT", "1") != "0"
 # inference on a grid too small to fill the chip (every conv launch < 256 workgroups: one 128 x 128 image is 128): the depth
 # and the colour stream of a block are independent up to the CAC gate -- run them on two HIP streams.  0 = one stream (A/B)
 TWO_STREAMS = _os.environ.get("CODON_TWO_STREAMS", "1") != "0"
+# ... largest grid (8 x 32-pixel tiles per conv launch of one stream) that still takes the two-stream schedule: fp32 kernels /
+# 16-bit kernels.  One 370 x 463 image is 705 tiles on 512 resident workgroup slots -- 1.4 rounds, i.e. two, the second a
+# third full; the depth and the colour launch of a block together are 2.75 rounds (profiles/r05_b1_*)
+TWO_STREAMS_MAX32 = int(_os.environ.get("CODON_TWO_STREAMS_MAX32", "256"))
+TWO_STREAMS_MAX16 = int(_os.environ.get("CODON_TWO_STREAMS_MAX16", "256"))
+# ... and up to this many tiles the two streams of a block leave as PAIR launches (ops.conv_pair: one grid of twice the tiles
+# instead of two launches on two HIP streams -- no fork / join events, the second stream fills the first one's last round)
+PAIR_MAX16 = int(_os.environ.get("CODON_PAIR_MAX16", "4096"))
+# the whole gate of a block -- pool finish, MLP, spatial conv -- in one launch (codon_cac_tail_fwd); 0 = three / four launches (A/B)
+CAC_TAIL = _os.environ.get("CODON_CAC_TAIL", "1") != "0"
 _HALF_STREAMS: Dict[tuple, tuple] = {}
 
 
@@ -568,22 +578,38 @@ class _CODONBase(nn.Module):
             else:
                 conv(plain_s, name, ys, k, relu=True)
 
-        f32 = lambda t: t if t.dtype == torch.float32 else t.float()   # small (<= 2 KB) parameters
+        # the small parameters the kernels take in fp32 (stems, head, the 25 gate tensors): themselves, or -- a model cast to
+        # 16 bits as a whole, test.py:52 -- one flat fp32 copy made by ONE launch per forward from the live parameters
+        gmods = [(getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")) for i in range(5)]
+        small = ops.params_f32([self.input.weight, self.input_c.weight, self.output.weight] +
+                               [t for ac, asp in gmods for t in (ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight,
+                                                                 ac.mlp[3].bias, asp.spatial.conv.weight)])
+        w_in, w_in_c, w_out = small[:3]
+        gparams = [small[3 + 5 * i: 8 + 5 * i] for i in range(5)]      # (w1, b1, w2, b2, ws) of block i
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
         in2 = new(128)
         t64 = new(64)
-        ops.stem(x, f32(self.input.weight), Slice(t64))
-        conv(Slice(t64), "conv_input", Slice(in2, 0, 64), 3, relu=True)
-        t64c = new(64) if keep else t64
-        ops.stem(y, f32(self.input_c.weight), Slice(t64c))
-        conv(Slice(t64c), "conv_input_c", Slice(in2, 64, 64), 3, relu=True)
+        ops.stem(x, w_in, Slice(t64))
+        # 16-bit inference on a grid of at most PAIR_MAX16 tiles: the depth and the colour conv of every stage as ONE launch
+        pairs = ops.is_c8(adt) and (not keep) and B * ((H + 7) // 8) * ((W + 31) // 32) <= PAIR_MAX16
+        pair = lambda: ops.conv_pair(dev, pairs)
+        t64c = new(64) if (keep or pairs) else t64
+        if pairs:
+            ops.stem(y, w_in_c, Slice(t64c))
+        with pair():
+            conv(Slice(t64), "conv_input", Slice(in2, 0, 64), 3, relu=True)
+            if not pairs:
+                ops.stem(y, w_in_c, Slice(t64c))
+            conv(Slice(t64c), "conv_input_c", Slice(in2, 64, 64), 3, relu=True)
         inputs, inputs_c = Slice(in2, 0, 64), Slice(in2, 64, 64)
         if keep:
             save["stem"], save["stem_c"], save["in2"] = t64, t64c, in2
 
         # small grids (inference): two HIP streams, fork before the streams of a block, join at its gate
-        two = TWO_STREAMS and (not keep) and dev.type == "cuda" and B * ((H + 3) // 4) * ((W + 31) // 32) <= 256
+        two = TWO_STREAMS and (not keep) and (not pairs) and dev.type == "cuda" and (
+            B * ((H + 7) // 8) * ((W + 31) // 32) <= TWO_STREAMS_MAX16 if ops.is_c8(adt) else
+            B * ((H + 3) // 4) * ((W + 31) // 32) <= TWO_STREAMS_MAX32)
         main_s = torch.cuda.current_stream(dev) if two else None
         halves = _half_chip_streams(dev, main_s) if two else None
         if two:
@@ -616,9 +642,12 @@ class _CODONBase(nn.Module):
 
         nt = ops.cac_fused_tiles(H, W) if fused_stats else ops.cac_stats_tiles(H, W)
         fz = dict(dtype=torch.float32, device=dev)
+        tail = CAC_TAIL and (fused_stats or nt <= L.CAC_FOLDS)     # fp32: identical sums only while every fold holds one tile
         if fused_stats:
             pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
+        if fused_stats or tail:
             folded = torch.empty((B, L.CAC_FOLDS, 128, 2), **fz)
+        counters = torch.zeros((B,), dtype=torch.int32, device=dev) if tail else None    # arrival counters: left at zero by every launch
         cur = in2                       # (B,128): [depth | colour] block input
         oc = prev_gate = prev_pre2 = None
         stage = r2 = stage_c = r2_c = pre2 = None
@@ -627,8 +656,8 @@ class _CODONBase(nn.Module):
             if keep or stage is None:
                 stage = stage if (drop_stage and stage is not None) else new(128)
                 r2, pre2 = new(128), new(128)
-                stage_c = (stage_c if (drop_stage and stage_c is not None) else new(128)) if keep else (new(128) if two else stage)
-                r2_c = new(128) if (keep or two) else r2
+                stage_c = (stage_c if (drop_stage and stage_c is not None) else new(128)) if keep else (new(128) if (two or pairs) else stage)
+                r2_c = new(128) if (keep or two or pairs) else r2
                 pooled = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
                 partials = torch.empty((B, nt, 128, 2), dtype=torch.float32, device=dev)
                 sp = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
@@ -643,29 +672,46 @@ class _CODONBase(nn.Module):
             if emit16 and keep and gate is not None:
                 xg = new(128)           # training: the emitted tensor is this block's saved input
             xg_d, xg_c = (Slice(xg, 0, 64), Slice(xg, 64, 64)) if (emit16 and gate is not None) else (None, None)
+            if pairs:
+                # stage by stage, colour | depth as one launch each (same kernel variant on the same grid)
+                with pair():
+                    gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
+                    gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
+                with pair():
+                    gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
+                    gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
+                with pair():
+                    conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c, stats=(pool_c, partials, 0))
+                    conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre, stats=(pool_d, partials, 64))
             with _on_half(1):
-                gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
-                gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
-                conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
-                          stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
+                if not pairs:
+                    gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)
+                    gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
+                    conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
+                              stats=(pool_c, partials, 0) if fused_stats else None)   # :82,83
             # depth stream: stage = [conv1 3x3 | conv2 5x5]                          :75,77,79
             with _on_half(0):
-                gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
-                gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
-                conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
-                          stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
+                if not pairs:
+                    gconv(gate, gpre, inputs, out, "conv2", Slice(stage, 64, 64), 5, emit=xg_d)
+                    gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
+                    conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
+                              stats=(pool_d, partials, 64) if fused_stats else None)   # :81,84
             join()
             # CAC gate on Fcat = [pre_c | pre]                                       :85-91
-            ac, asp = getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")
-            if fused_stats:
-                ops.cac_fused_finish(B, H, W, partials, pool_c, pool_d, folded, pooled)
-                ops.cac_gate_folded(B, H, W, folded, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
-                                    f32(ac.mlp[3].bias), ch, pools)
-            else:
+            w1_, b1_, w2_, b2_, ws_ = gparams[i]
+            if not fused_stats:
                 ops.cac_stats(pre_c, pre, pooled, partials)
-                ops.cac_gate(B, H, W, partials, f32(ac.mlp[1].weight), f32(ac.mlp[1].bias), f32(ac.mlp[3].weight),
-                             f32(ac.mlp[3].bias), ch, pools)
-            ops.cac_spatial(pooled, f32(asp.spatial.conv.weight), sp)
+            if tail:
+                # 16-bit inference has no other use for `pooled`: it is formed inside the spatial tiles and not written
+                ops.cac_tail(B, H, W, partials, pool_c if fused_stats else None, pool_d if fused_stats else None,
+                             pooled if (keep or not fused_stats) else None, folded, counters, w1_, b1_, w2_, b2_, ws_, ch, sp, pools)
+            else:
+                if fused_stats:
+                    ops.cac_fused_finish(B, H, W, partials, pool_c, pool_d, folded, pooled)
+                    ops.cac_gate_folded(B, H, W, folded, w1_, b1_, w2_, b2_, ch, pools)
+                else:
+                    ops.cac_gate(B, H, W, partials, w1_, b1_, w2_, b2_, ch, pools)
+                ops.cac_spatial(pooled, ws_, sp)
             if gated:
                 prev_gate, prev_pre2 = (ch, sp), pre2    # consumed by the next block's convs / conv7
             else:
@@ -710,7 +756,7 @@ class _CODONBase(nn.Module):
         t = new(64) if keep else t64
         conv(Slice(f), "conv11", Slice(t), 3, relu=True)
         outp = torch.empty_like(x)
-        ops.head(Slice(t), f32(self.output.weight), x, outp)
+        ops.head(Slice(t), w_out, x, outp)
         if keep:
             save["f_last"], save["t11"] = f, t
         return outp

@@ -132,6 +132,29 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
     return out
 
 
+class conv_pair:
+    """`with ops.conv_pair(dev):` -- the (up to two, mutually independent) conv calls of the body leave as ONE launch when
+    they run the same kernel on the same grid (codon_conv_pair_begin / _end); `.launches` = how many launches it took."""
+
+    def __init__(self, dev, enabled: bool = True):
+        self.dev, self.enabled, self.launches = dev, enabled, None
+
+    def __enter__(self):
+        if self.enabled:
+            L.check(L.load().codon_conv_pair_begin(), "conv_pair_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if not self.enabled:
+            return False
+        with torch.cuda.device(self.dev):
+            n = L.load().codon_conv_pair_end(_stream(self.dev))
+        if n < 0 and et is None:
+            L.check(n, "conv_pair_end")
+        self.launches = n
+        return False
+
+
 def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = False,
            residual: Optional[Slice] = None, accumulate: bool = False, relu_mask: Optional[Slice] = None,
            f16x3: bool = False, mask_sum: bool = False):
@@ -399,6 +422,47 @@ def cac_stats_tiles(H: int, W: int) -> int:
 
 def cac_fused_tiles(H: int, W: int) -> int:
     return L.load().codon_cac_fused_tiles(H, W)
+
+
+def params_f32(tensors):
+    """The given small parameter tensors as fp32: themselves when they already are, else views of ONE flat fp32 buffer
+    filled by one launch (codon_cast_multi) -- a 16-bit model's stems, head and gate tensors, read live on every call."""
+    tensors = list(tensors)
+    if all(t.dtype == torch.float32 for t in tensors):
+        return [t.detach() for t in tensors]
+    lib = L.load()
+    out, todo = [None] * len(tensors), list(range(len(tensors)))
+    while todo:
+        idx, todo = todo[:L.CAST_MAX], todo[L.CAST_MAX:]
+        dev = _dev(*[tensors[i] for i in idx])
+        d = L.CastDesc()
+        d.n = len(idx)
+        for j, i in enumerate(idx):
+            t = tensors[i]
+            d.src[j], d.count[j], d.dtype[j] = t.data_ptr(), t.numel(), _dt(t)
+        flat = torch.empty(sum(tensors[i].numel() for i in idx), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.codon_cast_multi(C.byref(d), _ptr(flat), _stream(dev)), "cast_multi")
+        off = 0
+        for i in idx:
+            n = tensors[i].numel()
+            out[i] = flat[off:off + n].view(tensors[i].shape)
+            off += n
+    return out
+
+
+def cac_tail(B: int, H: int, W: int, partials, pool_c, pool_d, pooled, folded, counters, w1, b1, w2, b2, ws, ch, sp,
+             pools_out=None):
+    """The whole gate of a block in one launch (codon_cac_tail_fwd): pool_c / pool_d given = the 16-bit path's two per-stream
+    maps (pooled, when not None, is WRITTEN); both None = the fp32 path (pooled is READ, as cac_stats left it)."""
+    lib = L.load()
+    dev = _dev(partials, pool_c, pool_d, pooled, folded, counters, w1, b1, w2, b2, ws, ch, sp, pools_out)
+    assert tuple(folded.shape) == (B, L.CAC_FOLDS, 128, 2) and counters.dtype == torch.int32 and counters.numel() >= B
+    assert partials.shape[0] == B and tuple(partials.shape[2:]) == (128, 2)
+    with torch.cuda.device(dev):
+        L.check(lib.codon_cac_tail_fwd(B, H, W, int(partials.shape[1]), _ptr(partials), _ptr(pool_c), _ptr(pool_d), _ptr(pooled),
+                                       _ptr(folded), _ptr(counters), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ws), _ptr(ch),
+                                       _ptr(pools_out), _ptr(sp), _stream(dev)), "cac_tail_fwd")
 
 
 def cac_fused_finish(B: int, H: int, W: int, partials, pool_c, pool_d, folded, pooled):

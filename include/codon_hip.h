@@ -161,6 +161,19 @@ int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t nti
                        const float* w1, const float* b1, const float* w2, const float* b2, const float* w_spatial, float* ch,
                        float* pools_out, float* sp, codon_stream_t stream);
 
+/* Two independent convs of one shape as ONE launch.  The depth and the colour stream of a block do not meet before the CAC
+ * gate (/root/reference/CODON_X4/CODON_x4.py:75-84: conv2 | conv4, conv1 | conv5, conv3 + confuse | conv6 + confuse_c), and
+ * at one image per call (test.py:116-125) each of their launches covers the chip only about once: issued as one grid of
+ * twice the tiles they fill each other's last round.  Between codon_conv_pair_begin() and codon_conv_pair_end(stream), on
+ * the calling host thread, up to two calls of codon_conv2d_fwd / codon_conv_chain1x1[_stats]_fwd / codon_conv2d_gated[_emit]_fwd
+ * are validated as usual but HELD BACK; pair_end issues them -- as one launch when both run the same kernel variant on the
+ * same grid (same shapes, dtype and epilogue kind), else one after the other -- and returns the number of launches issued
+ * (>= 0) or a negative codon_status.  The two calls must be independent (neither reads what the other writes).  Calls the
+ * pair form does not cover (1x1 convs, the resident-filter conv3x3 of large grids, fp32 convs that are not small-grid)
+ * launch at once, as without the bracket.  Same arithmetic per tile: results are bit-identical to separate launches. */
+int codon_conv_pair_begin(void);
+int codon_conv_pair_end(codon_stream_t stream);
+
 /* A conv whose input is the CAC gate-apply of the producing block, formed while the input tile is staged instead of
  * being written to HBM and read back (inference):   x = pre * (ch * sp) + inputs ,  y = conv(x) [ReLU]
  *   out*ad_CAC + inputs  /  out_c*ad_CAC + inputs_c  feeding conv1, conv2 / conv4, conv5 / conv7
@@ -428,6 +441,20 @@ typedef struct codon_wsum_desc {
 size_t codon_weight_checksum_workspace_bytes(void);
 int codon_weight_checksum(const codon_wsum_desc* desc, void* ws, uint64_t* ref, int32_t mode, int32_t* flag,
                           codon_stream_t stream);
+
+/* ---- the small fp32-arithmetic parameters of a 16-bit model as one flat fp32 buffer ------------------------------------
+ * `model.cuda().half()` (/root/reference/CODON_X4/test.py:52) keeps the stems, the head and the gate tensors in 16 bits;
+ * the kernels that use them take fp32.  One launch converts up to CODON_CAST_MAX tensors (count[t] elements of dtype[t],
+ * a codon_dtype) into dst, back to back in the order given; nothing is cached (the live parameters are read every time). */
+#define CODON_CAST_MAX 32
+typedef struct codon_cast_desc {
+  int32_t n;
+  int32_t reserved;
+  const void* src[CODON_CAST_MAX];
+  int64_t count[CODON_CAST_MAX];
+  int32_t dtype[CODON_CAST_MAX];
+} codon_cast_desc;
+int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream);
 
 #ifdef __cplusplus
 }

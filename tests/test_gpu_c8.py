@@ -748,3 +748,156 @@ def test_two_stream_schedule_is_bit_identical(dtype):
     assert torch.isfinite(outs[0]).all()
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("shape", [(1, 37, 70), (3, 64, 96), (2, 5, 3), (1, 370, 463)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_cac_tail_equals_the_separate_launches(shape, fused):
+    """codon_cac_tail_fwd (round 5: the whole gate of a block in one launch) against the launches it replaces, bit for bit:
+    fused = the 16-bit path's operands (two per-stream {max, sum} maps + per-conv-tile partials -> fold, combine, gate,
+    spatial); not fused = the fp32 path's (pooled + per-stats-tile partials, <= CODON_CAC_FOLDS tiles -> gate, spatial).
+    The arrival counters must come back as zeros, and a second launch on the same buffers must give the same bits."""
+    from codon_amd import _lib as L, ops
+    dev = _dev()
+    B, H, W = shape
+    nt = ops.cac_fused_tiles(H, W) if fused else ops.cac_stats_tiles(H, W)
+    if not fused and nt > L.CAC_FOLDS:
+        pytest.skip("fp32 path: the one-launch form is used up to CODON_CAC_FOLDS tiles")
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    partials = rnd(B, nt, 128, 2)
+    w1, b1, w2, b2, ws = rnd(8, 128) * 0.1, rnd(8) * 0.1, rnd(64, 8) * 0.3, rnd(64) * 0.1, rnd(1, 2, 5, 5) * 0.2
+    mk = lambda: (torch.empty((B, 64), device=dev), torch.empty((B, 1, H, W), device=dev), torch.empty((B, 2, 128), device=dev))
+    (ch0, sp0, po0), (ch1, sp1, po1) = mk(), mk()
+    folded = torch.empty((B, L.CAC_FOLDS, 128, 2), device=dev)
+    counters = torch.zeros((B,), dtype=torch.int32, device=dev)
+    if fused:
+        pool_c, pool_d = rnd(B, 2, H, W), rnd(B, 2, H, W)
+        pooled0 = torch.empty((B, 2, H, W), device=dev)
+        ops.cac_fused_finish(B, H, W, partials, pool_c, pool_d, folded, pooled0)
+        ops.cac_gate_folded(B, H, W, folded, w1, b1, w2, b2, ch0, po0)
+        ops.cac_spatial(pooled0, ws, sp0)
+        for pooled1 in (torch.full((B, 2, H, W), float("nan"), device=dev), None):       # training keeps pooled, inference does not
+            folded.fill_(float("nan"))
+            ops.cac_tail(B, H, W, partials, pool_c, pool_d, pooled1, folded, counters, w1, b1, w2, b2, ws, ch1, sp1, po1)
+            assert torch.equal(ch1, ch0) and torch.equal(sp1, sp0) and torch.equal(po1, po0)
+            assert pooled1 is None or torch.equal(pooled1, pooled0)
+            assert int(counters.abs().sum()) == 0
+    else:
+        pooled = rnd(B, 2, H, W)
+        ops.cac_gate(B, H, W, partials, w1, b1, w2, b2, ch0, po0)
+        ops.cac_spatial(pooled, ws, sp0)
+        for _ in range(2):
+            ops.cac_tail(B, H, W, partials, None, None, pooled, folded, counters, w1, b1, w2, b2, ws, ch1, sp1, po1)
+            assert torch.equal(ch1, ch0) and torch.equal(sp1, sp0) and torch.equal(po1, po0)
+            assert int(counters.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_small_parameters_as_one_flat_fp32_buffer(dtype):
+    """ops.params_f32 (codon_cast_multi): 28 tensors of a model cast to 16 bits -> fp32 in one launch, exact."""
+    from codon_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    shapes = [(64, 1, 3, 3), (64, 1, 3, 3), (1, 64, 3, 3)] + [(8, 128), (8,), (64, 8), (64,), (1, 2, 5, 5)] * 5 + [(3,)] * 9
+    ts = [torch.randn(s, generator=g).to(dtype).to(dev) for s in shapes]          # 37 tensors: more than one launch's worth
+    out = ops.params_f32(ts)
+    assert len(out) == len(ts)
+    for o, t in zip(out, ts):
+        assert o.dtype == torch.float32 and o.shape == t.shape and torch.equal(o, t.float())
+    if dtype == torch.float32:
+        assert all(o.data_ptr() == t.data_ptr() for o, t in zip(out, ts))        # nothing to convert: the parameters themselves
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16", "fp32"])
+def test_forward_with_one_launch_gate_and_two_streams_is_bit_identical(mode):
+    """The schedule switches of round 5 change launches, not arithmetic: the one-launch gate (CAC_TAIL) and the two-stream
+    schedule at a grid between the old and the new threshold (TWO_STREAMS_MAX16) leave every output bit in place."""
+    import codon_amd
+    from codon_amd import model as M
+    dev = _dev()
+    torch.manual_seed(3)
+    net = codon_amd.CODONNet().to(dev).eval()
+    if mode == "fp16":
+        net = net.half()
+    elif mode == "bf16":
+        net.set_compute_dtype(torch.bfloat16)
+    H, W = (96, 128) if mode != "fp32" else (64, 96)          # fp32: 6 stats tiles <= CODON_CAC_FOLDS
+    x = torch.rand((1, 1, H, W), device=dev)
+    y = torch.rand((1, 1, H, W), device=dev)
+    if mode == "fp16":
+        x, y = x.half(), y.half()
+    old = (M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16)
+    outs = []
+    try:
+        for tail, m16, m32, pr in ((False, 0, 0, 0), (True, 0, 0, 0), (True, 4096, 4096, 0), (False, 4096, 4096, 0),
+                                   (True, 0, 0, 4096), (False, 4096, 4096, 4096)):
+            M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16 = tail, m16, m32, pr
+            with torch.no_grad():
+                outs.append(net(x, y).clone())
+            torch.cuda.synchronize()
+    finally:
+        M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16 = old
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_pair_is_one_launch_and_bit_identical(dtype):
+    """ops.conv_pair (codon_conv_pair_begin / _end): two independent convs of one shape leave as ONE launch with the bits of
+    two launches -- plain, chained 1x1 with statistics, gated + emitting; different shapes / kernels fall back to two
+    launches; a bracket is per thread and cannot nest."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 1, 37, 70
+    q = lambda c, seed: ops.from_nchw(_rand((B, c, H, W), seed).to(dtype).float().to(dev), dtype)
+    xa, xb = q(128, 1), q(128, 2)
+    wt = lambda co, ci, k, seed: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), L.PACK_FWD, dtype)
+    w5a, w5b, w3a, w3b = wt(64, 64, 5, 3), wt(64, 64, 5, 4), wt(64, 64, 3, 5), wt(64, 64, 3, 6)
+
+    def run(paired):
+        outs = [ops.new_act(B, 128, H, W, dtype, dev).zero_() for _ in range(4)]
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[0], 64, 64), 5, relu=True)
+            ops.conv2d(Slice(xb, 64, 64), w5b, Slice(outs[1], 0, 64), 5, relu=True)
+        n1 = pr.launches
+        with ops.conv_pair(dev, paired) as pr:             # a 5x5 and a 3x3: not one kernel -> two launches
+            ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[2], 0, 64), 5)
+            ops.conv2d(Slice(xb, 0, 64), w3b, Slice(outs[2], 64, 64), 3)
+        n2 = pr.launches
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d(Slice(xa, 64, 64), w3a, Slice(outs[3], 0, 64), 3, relu=True)
+            ops.conv2d(Slice(xb, 0, 64), w3b, Slice(outs[3], 64, 64), 3, relu=True)
+        return outs, (n1, n2, pr.launches)
+
+    o0, _ = run(False)
+    o1, n = run(True)
+    assert n == (1, 2, 1), n
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1))
+    # chained 1x1 + statistics, and gated + emitting, as pairs
+    w5 = wt(128, 128, 5, 7)
+    w1 = ops.packed_weight(_rand((64, 128, 1, 1), 8, 0.1).to(dev), L.PACK_CHAIN1X1, dtype)
+    ch, sp = torch.rand((B, 64), device=dev), torch.rand((B, 1, H, W), device=dev)
+    nt = ops.cac_fused_tiles(H, W)
+
+    def run2(paired):
+        pre = ops.new_act(B, 128, H, W, dtype, dev).zero_()
+        pc, pd = torch.zeros((B, 2, H, W), device=dev), torch.zeros((B, 2, H, W), device=dev)
+        part = torch.zeros((B, nt, 128, 2), device=dev)
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv_chain1x1(Slice(xa), w5, w1, Slice(pre, 64, 64), stats=(pc, part, 0))
+            ops.conv_chain1x1(Slice(xb), w5, w1, Slice(pre, 0, 64), stats=(pd, part, 64))
+        n1 = pr.launches
+        y, em = ops.new_act(B, 128, H, W, dtype, dev).zero_(), ops.new_act(B, 128, H, W, dtype, dev).zero_()
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d_gated(Slice(pre, 64, 64), Slice(xa, 64, 64), ch, sp, w5a, Slice(y, 0, 64), 5, relu=True, emit=Slice(em, 64, 64))
+            ops.conv2d_gated(Slice(pre, 0, 64), Slice(xa, 0, 64), ch, sp, w5b, Slice(y, 64, 64), 5, relu=True, emit=Slice(em, 0, 64))
+        return (pre, pc, pd, part, y, em), (n1, pr.launches)
+
+    r0, _ = run2(False)
+    r1, n = run2(True)
+    assert n == (1, 1), n
+    assert all(torch.equal(a, b) for a, b in zip(r0, r1))
+    with ops.conv_pair(dev):
+        with pytest.raises(RuntimeError, match="already inside a pair"):
+            L.check(L.load().codon_conv_pair_begin(), "conv_pair_begin")
