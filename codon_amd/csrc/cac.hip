@@ -221,7 +221,83 @@ static bool aligned16(const void* a, const void* b = nullptr, const void* c = nu
            reinterpret_cast<uintptr_t>(d)) % 16) == 0;
 }
 
-int cac_stats_tiles(int H, int W) { return (int)(((long)H * W + STATS_TILE - 1) / STATS_TILE); }
+// SMALL IMAGES (one 128 x 128 pair per call, BASELINE configs[0]): 2048-pixel tiles make 8 workgroups that walk 128 planes in
+// 16 dependent trips -- 57 us of a 2.9 ms forward on a chip with 256 CUs (profiles/r05_b1_fp32_128x128_timeline.txt).  Up to
+// STATS_SMALL_HW pixels a tile is 256 pixels (one per thread, 64 workgroups for 128 x 128) and a trip holds 32 planes.  The
+// choice depends on H * W only, never on the batch: an image's statistics do not depend on what else is in the batch.
+constexpr long STATS_SMALL_HW = 32768;
+constexpr int STATS_SMALL_TILE = 256;
+static bool stats_small(long HW) { return HW <= STATS_SMALL_HW; }
+int cac_stats_tiles(int H, int W) {
+  const long HW = (long)H * W;
+  return stats_small(HW) ? (int)((HW + STATS_SMALL_TILE - 1) / STATS_SMALL_TILE) : (int)((HW + STATS_TILE - 1) / STATS_TILE);
+}
+
+// Wave-wide sum / max by DPP (row rotations inside the 16-lane rows, then the two row broadcasts): six VALU instructions, the
+// result in LANE 63.  __shfl_xor goes through ds_bpermute -- 1536 dependent LDS-crossbar round trips per thread for the 128
+// channels of a pixel took 25 of this kernel's 37 us.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_red63(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, dpp_take<0xB1>(v));            // quad_perm [1,0,3,2]
+  v = op(v, dpp_take<0x4E>(v));            // quad_perm [2,3,0,1]
+  v = op(v, dpp_take<0x124>(v));           // row_ror:4
+  v = op(v, dpp_take<0x128>(v));           // row_ror:8   -> every lane holds its row's result
+  v = op(v, dpp_take<0x142, 0xa>(v));      // row_bcast:15 into rows 1, 3
+  v = op(v, dpp_take<0x143, 0xc>(v));      // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's
+  return v;
+}
+
+// grid = (ntiles, B), 256 threads, thread = pixel.  Same outputs as cac_stats_kernel (per-pixel channel max / mean, per-tile
+// per-channel {sum, max}); sums in a different (fixed) order: DPP tree per channel and wave, then the four waves.
+__global__ __launch_bounds__(256) void cac_stats_small_kernel(const float* __restrict__ pre_c, long pc_img,
+                                                              const float* __restrict__ pre, long p_img,
+                                                              float* __restrict__ pooled, float* __restrict__ partials,
+                                                              long HW, int ntiles, const float* __restrict__ chs) {
+  __shared__ float red[128][4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const long q = (long)tile * STATS_SMALL_TILE + tid;
+  const bool ok = q < HW;
+  const long qq = ok ? q : 0;                       // unconditional loads from a valid address, masked below
+  float pmax = -INFINITY, psum = 0.f;
+  constexpr int CB = 32;
+#pragma unroll 1
+  for (int c0 = 0; c0 < 128; c0 += CB) {
+    float v[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int c = c0 + j;
+      v[j] = (c < 64 ? pre_c + b * pc_img + c * HW : pre + b * p_img + (c - 64) * HW)[qq];
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int c = c0 + j;
+      float x = v[j];
+      if (chs) x *= chs[b * 64 + (c & 63)];
+      pmax = fmaxf(pmax, x);
+      psum += x;
+      const float s = wave_red63<false>(ok ? x : 0.f), m = wave_red63<true>(ok ? x : -INFINITY);
+      if (lane == 63) { red[c][wave][0] = s; red[c][wave][1] = m; }
+    }
+  }
+  if (ok) {
+    float* pm = pooled + (long)b * 2 * HW;
+    pm[q] = pmax;
+    pm[HW + q] = psum * (1.f / 128.f);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const float s = (red[tid][0][0] + red[tid][1][0]) + (red[tid][2][0] + red[tid][3][0]);
+    const float m = fmaxf(fmaxf(red[tid][0][1], red[tid][1][1]), fmaxf(red[tid][2][1], red[tid][3][1]));
+    float2* out = reinterpret_cast<float2*>(partials + (((long)b * ntiles + tile) * 128 + tid) * 2);
+    *out = make_float2(s, m);
+  }
+}
 
 int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled,
                   float* partials, int dtype, hipStream_t stream, const float* chs) {
@@ -232,6 +308,11 @@ int cac_stats_fwd(int B, int H, int W, const codon_tensor* pc, const codon_tenso
   const size_t es = 4;
   const char* pre_c = (const char*)pc->data + pc->coff * HW * es;
   const char* pre = (const char*)pd->data + pd->coff * HW * es;
+  if (stats_small(HW)) {
+    hipLaunchKernelGGL(cac_stats_small_kernel, dim3(nt, B), dim3(256), 0, stream, (const float*)pre_c, pc->ctotal * HW,
+                       (const float*)pre, pd->ctotal * HW, pooled, partials, HW, nt, chs);
+    return check_launch("cac_stats_small_kernel");
+  }
   px_dispatch(dtype, HW, aligned16(pre_c, pre, pooled), [&](auto pol) {
     using P = decltype(pol);
     hipLaunchKernelGGL(cac_stats_kernel<P>, dim3(nt, B), dim3(256), 0, stream, (const typename P::T*)pre_c,

@@ -118,10 +118,15 @@ __global__ __launch_bounds__(256) void cac_bwd_reduce_kernel(Sl<typename P::T> g
 }
 
 // ---- B -------------------------------------------------------------------------------------------
-// grid = B, 128 threads.  param partial layout per image: w1 (8x128) | b1 (8) | w2 (64x8) | b2 (64) = 1608
+// grid = B.  param partial layout per image: w1 (8x128) | b1 (8) | w2 (64x8) | b2 (64) = 1608
 constexpr int GATE_NPARAM = 8 * 128 + 8 + 64 * 8 + 64;
 
-__global__ __launch_bounds__(128) void cac_bwd_gate_kernel(const float* __restrict__ part_gch,
+// 1024 threads = 128 channels x 8 slices of the tile range (round 5): the two walks over the per-tile partials -- the arg-max
+// pixel of every channel, the 64 gate-gradient sums -- were ONE thread per channel stepping through 1200 tiles (480 x 640):
+// 97 us per launch, latency.  Each slice walks its contiguous share, the eight results meet in LDS in slice order (fixed
+// order: deterministic; min is exact, the sums are re-associated once).
+constexpr int GATE_SLICES = 8;
+__global__ __launch_bounds__(128 * GATE_SLICES) void cac_bwd_gate_kernel(const float* __restrict__ part_gch,
                                                            const int* __restrict__ part_arg,
                                                            const float* __restrict__ ch,
                                                            const float* __restrict__ pools,
@@ -132,15 +137,33 @@ __global__ __launch_bounds__(128) void cac_bwd_gate_kernel(const float* __restri
                                                            float* __restrict__ part_param, // (B,1608)
                                                            int ntiles) {
   __shared__ float pool[2][128], gs[64], hid[2][8], ghid[2][8];
-  const int t = threadIdx.x, b = blockIdx.x;
+  __shared__ int s_am[GATE_SLICES][128];
+  __shared__ float s_gs[GATE_SLICES][64];
+  const int t = threadIdx.x & 127, sl = threadIdx.x >> 7, b = blockIdx.x;
+  {
+    const int per = (ntiles + GATE_SLICES - 1) / GATE_SLICES;
+    const int k0 = sl * per, k1 = min(k0 + per, ntiles);
+    int am = INT_MAX;
+    for (int k = k0; k < k1; ++k) am = min(am, part_arg[((long)b * ntiles + k) * 128 + t]);
+    s_am[sl][t] = am;
+    if (t < 64) {
+      float s = 0.f;
+      for (int k = k0; k < k1; ++k) s += part_gch[((long)b * ntiles + k) * 64 + t];
+      s_gs[sl][t] = s;
+    }
+  }
+  __syncthreads();
+  if (sl != 0) return;                      // (no barrier below is reached by a subset: the other slices are done)
   pool[0][t] = pools[((long)b * 2 + 0) * 128 + t];
   pool[1][t] = pools[((long)b * 2 + 1) * 128 + t];
-  int am = INT_MAX;
-  for (int k = 0; k < ntiles; ++k) am = min(am, part_arg[((long)b * ntiles + k) * 128 + t]);
+  int am = s_am[0][t];
+#pragma unroll
+  for (int q = 1; q < GATE_SLICES; ++q) am = min(am, s_am[q][t]);
   argpix[(long)b * 128 + t] = am;
   if (t < 64) {
-    float s = 0.f;
-    for (int k = 0; k < ntiles; ++k) s += part_gch[((long)b * ntiles + k) * 64 + t];
+    float s = s_gs[0][t];
+#pragma unroll
+    for (int q = 1; q < GATE_SLICES; ++q) s += s_gs[q][t];
     const float c = ch[(long)b * 64 + t];
     gs[t] = s * c * (1.f - c);
   }
@@ -429,7 +452,7 @@ int cac_bwd_gate(int B, int H, int W, const float* part_gch, const int* part_arg
                  const float* pools, const float* w1, const float* b1, const float* w2, float* g_pools, int* argpix,
                  float* part_param, float* dw1, float* db1, float* dw2, float* db2, hipStream_t stream) {
   const int nt = cac_bwd_tiles(H, W);
-  hipLaunchKernelGGL(cac_bwd_gate_kernel, dim3(B), dim3(128), 0, stream, part_gch, part_arg, ch, pools, w1, b1, w2,
+  hipLaunchKernelGGL(cac_bwd_gate_kernel, dim3(B), dim3(128 * GATE_SLICES), 0, stream, part_gch, part_arg, ch, pools, w1, b1, w2,
                      g_pools, argpix, part_param, nt);
   int st = check_launch("cac_bwd_gate_kernel");
   if (st != CODON_OK || !dw1) return st;       // dw1 == null: the rows stay in part_param for codon_reduce_multi

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "codon_common.h"
+#include "pair.h"
 
 namespace codon {
 
@@ -107,10 +108,11 @@ int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*,
 
 int reduce_multi(const codon_reduce_item*, int, hipStream_t);
 int cast_multi(const codon_cast_desc*, float*, hipStream_t);
-int conv_pair_begin_16();
-int conv_pair_end_16(hipStream_t);
 size_t weight_checksum_workspace_bytes();
 int weight_checksum(const codon_wsum_desc*, void*, unsigned long long*, int, int*, hipStream_t);
+
+static thread_local PairRecorder g_pair;
+PairRecorder* pair_recorder() { return g_pair.active ? &g_pair : nullptr; }
 
 static bool slice_ok(const codon_tensor* t) { return t && t->data && t->coff >= 0 && t->coff + 64 <= t->ctotal; }
 
@@ -510,9 +512,31 @@ int codon_conv1ch_wgrad(int32_t batch, int32_t height, int32_t width, const codo
                        workspace_bytes, dtype, (hipStream_t)stream);
 }
 
-int codon_conv_pair_begin(void) { return conv_pair_begin_16(); }
+int codon_conv_pair_begin(void) {
+  CODON_REQUIRE(!g_pair.active, CODON_ERR_BAD_ARG, "conv_pair_begin: already inside a pair on this thread");
+  g_pair.active = true;
+  g_pair.n = 0;
+  return CODON_OK;
+}
 
-int codon_conv_pair_end(codon_stream_t stream) { return conv_pair_end_16((hipStream_t)stream); }
+int codon_conv_pair_end(codon_stream_t stream) {
+  CODON_REQUIRE(g_pair.active, CODON_ERR_BAD_ARG, "conv_pair_end without conv_pair_begin on this thread");
+  g_pair.active = false;
+  const int n = g_pair.n;
+  g_pair.n = 0;
+  const PairCall& a = g_pair.call[0];
+  const PairCall& b = g_pair.call[1];
+  if (n == 2 && a.pair == b.pair && a.nblk == b.nblk && a.tiles_x == b.tiles_x && a.tiles_y == b.tiles_y &&
+      (long)a.nblk * 2 < (1L << 31)) {
+    const int st = a.pair(a.blob, b.blob, (hipStream_t)stream);
+    return st == CODON_OK ? 1 : st;
+  }
+  for (int k = 0; k < n; ++k) {
+    const int st = g_pair.call[k].single(g_pair.call[k].blob, (hipStream_t)stream);
+    if (st != CODON_OK) return st;
+  }
+  return n;
+}
 
 int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream) {
   CODON_REQUIRE(desc && dst, CODON_ERR_BAD_ARG, "cast_multi: null pointer");

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "c8.h"
+#include "pair.h"
 
 namespace codon {
 
@@ -208,12 +209,16 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
 
   // the next chunk's halo tile is requested in two halves, during the last two filter rows of the current chunk
   constexpr int XE1 = XE / 2, XEH = XE - XE1;
-  constexpr bool DMA = C8_DMA && !GATE;
+  constexpr bool DMA = C8_DMA && !GATE;      // the halo tile: by LDS-DMA, or -- GATE: the gate arithmetic needs the VALU -- through registers
+  // (the weight rows of a GATE kernel by LDS-DMA while x goes through registers: measured in round 5, 1.80 vs 1.74 ms gated,
+  // 1.98 vs 1.91 gated + emitting -- the vmcnt(0) in front of the barrier then also waits for the emit stores;
+  // tools/probes/gate_weights_dma_experiment.patch)
+  constexpr bool DMAW = DMA;
   typedef __attribute__((address_space(3))) void lds_void;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   u32x4 xv[DMA ? 1 : XEH];
   u32x4 xg[GATE ? XEH : 1];
-  u32x4 wr[DMA ? 1 : WE];
+  u32x4 wr[DMAW ? 1 : WE];
 
 #define LOAD_XP(rs_, off_, chunk_, buf_, k0_, k1_)                                      \
   {                                                                                     \
@@ -257,7 +262,7 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
   if constexpr (!RESW) {                                                                \
     const unsigned so_ = (unsigned)(stage_) * (unsigned)(WS * 16);                      \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) {                                    \
-      if constexpr (DMA) {                                                              \
+      if constexpr (DMAW) {                                                              \
         if (WS % NT == 0 || k < WE - 1 || k * NT + wave_u * 64 < WS)                    \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(lds + 2 * XSP + (buf_) * WSP + k * NT + wave_u * 64), 16, \
                                                    k == WE - 1 ? wvo_last : wvo, so_ + k * (unsigned)(NT * 16), 0, 0); \
@@ -267,7 +272,7 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
     }                                                                                   \
   }
 #define STORE_W(buf_)                                                                   \
-  if constexpr (!DMA) {                                                                 \
+  if constexpr (!DMAW) {                                                                 \
     _Pragma("unroll") for (int k = 0; k < WE; ++k) ww[(buf_) * WSP + k * NT] = wr[k];   \
   }
 
@@ -292,7 +297,7 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
   }
   STORE_X(0, 0, XE1, XE);
   STORE_W(0);
-  if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this wave's pieces have landed
+  if constexpr (DMAW) __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): this wave's pieces have landed
   __syncthreads();
 
   static_assert(!PERSIST || (NST % 2 == 0), "the tile loop re-enters with stage parity 0");
@@ -403,7 +408,7 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
       }
       // RESW: nothing changes hands inside a chunk -- one barrier per chunk, the one that publishes the next halo tile
       if constexpr (!RESW || dy == KS - 1) {
-        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) before the barrier: DMA pieces of the next stage are in LDS
+        if constexpr (DMAW) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) before the barrier: DMA pieces of the next stage are in LDS
         __syncthreads();
       }
     });
@@ -935,58 +940,20 @@ static int c8_resident_blocks(K kernel, int threads) {
 // path wants many short workgroups).  (The tile loop with STAGED weights, for the plain 3x3 and 5x5 64->64 convs, was
 // measured as a loss and is gone: tools/probes/conv_c8_persist_staged_experiment.patch, profiles/HISTORY.md.)
 constexpr int C8_RESIDENT_MIN_TILES = 8;
-// codon_pair_begin / codon_pair_end (per host thread): conv launches of the staged one-tile-per-workgroup kernels issued in
-// between are held back here and leave as a pair
-struct PairRecorder {
-  struct Call {
-    ConvC8Params p;
-    int (*single)(const ConvC8Params&, hipStream_t);
-    int (*pair)(const ConvC8Params&, const ConvC8Params&, hipStream_t);
-  };
-  bool active = false;
-  int n = 0;
-  Call call[2];
-};
-static thread_local PairRecorder g_pair;
-static PairRecorder* pair_recorder() { return g_pair.active ? &g_pair : nullptr; }
-
 template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
-static int launch_single_c8(const ConvC8Params& p, hipStream_t stream) {
+static int launch_single_c8(const void* pv, hipStream_t stream) {
+  const ConvC8Params& p = *static_cast<const ConvC8Params*>(pv);
   hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)p.nblk), dim3(64 * NW), 0, stream, p);
   return check_launch("conv_c8_kernel");
 }
 template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
-static int launch_pair_c8(const ConvC8Params& a, const ConvC8Params& b, hipStream_t stream) {
+static int launch_pair_c8(const void* av, const void* bv, hipStream_t stream) {
   ConvC8Pair pp;
-  pp.a = a; pp.b = b;
-  hipLaunchKernelGGL((conv_c8_pair_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3(2u * (unsigned)a.nblk), dim3(64 * NW), 0,
+  pp.a = *static_cast<const ConvC8Params*>(av);
+  pp.b = *static_cast<const ConvC8Params*>(bv);
+  hipLaunchKernelGGL((conv_c8_pair_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3(2u * (unsigned)pp.a.nblk), dim3(64 * NW), 0,
                      stream, pp);
   return check_launch("conv_c8_pair_kernel");
-}
-
-int conv_pair_begin_16() {
-  CODON_REQUIRE(!g_pair.active, CODON_ERR_BAD_ARG, "pair_begin: already inside a pair on this thread");
-  g_pair.active = true;
-  g_pair.n = 0;
-  return CODON_OK;
-}
-// returns the number of launches issued (0, 1 or 2) or a negative status
-int conv_pair_end_16(hipStream_t stream) {
-  CODON_REQUIRE(g_pair.active, CODON_ERR_BAD_ARG, "pair_end without pair_begin on this thread");
-  g_pair.active = false;
-  const int n = g_pair.n;
-  g_pair.n = 0;
-  if (n == 2 && g_pair.call[0].pair == g_pair.call[1].pair && g_pair.call[0].p.nblk == g_pair.call[1].p.nblk &&
-      g_pair.call[0].p.tiles_x == g_pair.call[1].p.tiles_x && g_pair.call[0].p.tiles_y == g_pair.call[1].p.tiles_y &&
-      (long)g_pair.call[0].p.nblk * 2 < (1L << 31)) {
-    const int st = g_pair.call[0].pair(g_pair.call[0].p, g_pair.call[1].p, stream);
-    return st == CODON_OK ? 1 : st;
-  }
-  for (int k = 0; k < n; ++k) {
-    const int st = g_pair.call[k].single(g_pair.call[k].p, stream);
-    if (st != CODON_OK) return st;
-  }
-  return n;
 }
 
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
@@ -1014,18 +981,11 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
       return check_launch("conv_c8_kernel<resident>");
     }
   }
-  if (PairRecorder* r = pair_recorder()) {
-    // inside codon_pair_begin / codon_pair_end: hold the launch back; pair_end issues two held launches of the same
-    // kernel variant on the same grid as ONE, anything else one by one in the order they came
-    if (r->n < 2) {
-      PairRecorder::Call& c = r->call[r->n++];
-      c.p = p;
-      c.single = &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>;
-      c.pair = &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>;
-      return CODON_OK;
-    }
-  }
-  return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>(p, stream);
+  // inside codon_conv_pair_begin / _end the launch is held back: pair_end issues two held launches of the same kernel variant
+  // on the same grid as ONE, anything else one by one in the order they came
+  if (pair_hold(p, &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>, &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>))
+    return CODON_OK;
+  return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>(&p, stream);
 }
 
 template <class E>

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "codon_common.h"
+#include "pair.h"
 
 namespace codon {
 
@@ -103,8 +104,10 @@ enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 
 // NW = waves per workgroup: 4 (8 x 32 tile, two workgroups per CU) or 8 (16 x 32 tile, one 8-wave workgroup per CU:
 // the halo is 20 x 36 / (16 x 32) = 1.41x the tile instead of 1.69x, and the weight stage is staged once per CU).
+// The body takes the parameter block by reference and its (XCD-remapped) tile index as an argument: the same code serves the
+// one-conv launch and the pair launch (conv_mfma_f32_pair_kernel).
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid) {
   constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = NW * PSEG;
@@ -131,7 +134,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   const int half = lane >> 5;
 
   CODON_TSTAMP(p.dbg, 0)
-  unsigned bid = xcd_remap(blockIdx.x, (unsigned)p.nblk);
   const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
@@ -470,6 +472,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
   CODON_TSTAMP(p.dbg, 4)
 }
 
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvParams p) {
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW>(p, xcd_remap(blockIdx.x, (unsigned)p.nblk));
+}
+
+// Two convs of one shape and kernel variant as ONE grid of 2 * nblk workgroups (codon_conv_pair_begin / _end): the depth and
+// the colour stream of a block (/root/reference/CODON_X4/CODON_x4.py:75-84) at one image per call -- BASELINE configs[0]: two
+// launches of 128 workgroups on two HIP streams cost 12 + 18 us of fork / join events per block
+// (profiles/r05_b1_fp32_128x128_timeline.txt); one grid of 256 workgroups has no seam.  Same code per tile: same bits.
+struct ConvPair {
+  ConvParams a, b;
+};
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_pair_kernel(const ConvPair pp) {
+  const unsigned nblk = (unsigned)pp.a.nblk;                       // == pp.b.nblk (checked on the host)
+  const unsigned v = xcd_remap(blockIdx.x, 2u * nblk);
+  const bool second = v >= nblk;                                   // workgroup-uniform
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW>(second ? pp.b : pp.a, second ? v - nblk : v);
+}
+
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
 __global__ void pack_weight_f32_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
                                        int cin, int ks, int ck, int dgrad) {
@@ -519,8 +541,8 @@ static bool small_grid(const codon_conv_desc* d) {
 // dispatcher puts the workgroups of two concurrent 128-workgroup launches on the SAME CUs (rocprofv3 trace: both overlap in
 // time and each takes 345 us instead of 202).  A dynamic-LDS request that brings a workgroup above half of the CU's 160 KB
 // makes every workgroup the only one on its CU, so a concurrent launch must take the free CUs.  Bytes of padding for `kernel`.
-template <class K>
-static unsigned solo_lds_pad(K kernel) {
+template <auto kernel>            // a template VALUE: one table per kernel instantiation (a type parameter would share one between all
+static unsigned solo_lds_pad() {  // kernels of the same signature, i.e. give every kernel the padding of the first one that ran)
   // hipFuncSetAttribute acts on the CURRENT device's function object: one slot per (kernel instantiation, device), so
   // every GPU of a single-process multi-GPU caller (nn.DataParallel, per-device threads) raises its own limit before its
   // first padded launch.  A racing first call on a device computes and stores the same value.
@@ -550,6 +572,39 @@ static unsigned solo_lds_pad(K kernel) {
   return (unsigned)pad;
 }
 
+// one launch of a filled parameter block / two blocks of the same variant as one grid (pair.h).  `small` launches ask for the
+// solo-LDS padding so that every workgroup has a CU to itself.
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO>
+static int launch_single_f32(const void* pv, hipStream_t stream) {
+  const ConvParams& p = *static_cast<const ConvParams*>(pv);
+  const unsigned dyn = SOLO ? solo_lds_pad<conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>>() : 0u;
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>), dim3((unsigned)p.nblk), dim3(NW * 64), dyn, stream, p);
+  return check_launch("conv_mfma_f32_kernel");
+}
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO>
+static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
+  ConvPair pp;
+  pp.a = *static_cast<const ConvParams*>(av);
+  pp.b = *static_cast<const ConvParams*>(bv);
+  const unsigned dyn = SOLO ? solo_lds_pad<conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>>() : 0u;
+  hipLaunchKernelGGL((conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>), dim3(2u * (unsigned)pp.a.nblk),
+                     dim3(NW * 64), dyn, stream, pp);
+  return check_launch("conv_mfma_f32_pair_kernel");
+}
+// small-grid launches (PSEG = 1) can be held back by an open pair bracket; everything else launches at once
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW>
+static int launch_or_hold_f32(const ConvParams& p, bool small, hipStream_t stream) {
+  if constexpr (PSEG == 1) {
+    if (small) {
+      if (pair_hold(p, &launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>,
+                    &launch_pair_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>))
+        return CODON_OK;
+      return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>(&p, stream);
+    }
+  }
+  return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, false>(&p, stream);
+}
+
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* w, float* y,
                          const float* res, hipStream_t stream) {
@@ -574,9 +629,7 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.gout = nullptr; p.go_img = p.go_base = 0;
-  const unsigned dyn = (PSEG == 1 && small_grid(d)) ? solo_lds_pad(conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>) : 0u;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG>), dim3((unsigned)nblk), dim3(256), dyn, stream, p);
-  return check_launch("conv_mfma_f32_kernel");
+  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && small_grid(d), stream);
 }
 
 template <int KS, int CIN, int COUT, int PSEG>
@@ -614,9 +667,7 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  const unsigned dyn = (PSEG == 1 && small_grid(d)) ? solo_lds_pad(conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>) : 0u;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, false, true>), dim3((unsigned)nblk), dim3(256), dyn, stream, p);
-  return check_launch("conv_mfma_f32_kernel<gated>");
+  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, true, 4>(p, PSEG == 1 && small_grid(d), stream);
 }
 
 template <int KS, int CIN, int COUT>
@@ -667,12 +718,8 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  if (small)
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64),
-                       solo_lds_pad(conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC>), stream, p);
-  else
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<5, 128, 128, 2, true, false, NWC>), dim3((unsigned)nblk), dim3(NWC * 64), 0, stream, p);
-  return check_launch("conv_mfma_f32_kernel<fused 1x1>");
+  if (small) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, true, stream);
+  return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC>(p, false, stream);
 }
 
 // pixel rows per wave: 2 = 8 x 32 tile (4 operand fetches per 4 MFMAs) everywhere; the 16 x 32 tile (6 per 8) was measured on the

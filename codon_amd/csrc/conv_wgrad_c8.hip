@@ -26,6 +26,13 @@
 namespace codon {
 
 constexpr int WC8_TH = 4;
+// k = 5, round 5 A/B: rows of a staged tile.  8 = the x halo is 12 rows for 8 (1.5x) instead of 8 for 4 (2x) -- the HBM / L2 traffic
+// of the launch falls from ~1.5x to ~1.25x its algorithmic bytes -- in TWO buffers of twice the size (122 KB of LDS): the DMA of tile
+// t+2 still has two 4-row tile times to land, and there are half as many publishing barriers
+#ifndef CODON_WC8_TH5
+#define CODON_WC8_TH5 4
+#endif
+template <int KS> struct Wc8Th { static constexpr int value = KS == 5 ? CODON_WC8_TH5 : WC8_TH; };
 constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
 // k = 3: cin tiles per workgroup, each with its own 2*KS waves: 2 -> 64 cout x 64 cin, 12 waves = 3 per SIMD (balanced),
 // twice the MFMAs per staged byte and per barrier
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
   constexpr bool BAL = (KS == 5);                      // row waves take KS-1 taps, two column waves the last one
   constexpr int NROWW = Wc8Waves<KS>::rows, NTAP = BAL ? KS - 1 : KS;
   constexpr int PAD = KS / 2;
-  constexpr int TW = 32, TH = WC8_TH;
+  constexpr int TW = 32, TH = Wc8Th<KS>::value;
   constexpr int XC = KSPLIT ? TW : TW + 4;       // tile columns: origin tx0 - PAD; the 12-pixel windows reach column 35
   constexpr int XR = TH + KS - 1;
   constexpr int XPL = 4 * CIB, GPL = 8;          // 8-channel planes per tile
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
   // land; the wait in front of the publishing barrier leaves the youngest tile's pieces in flight (counted vmcnt: every
   // wave issues exactly PPW pieces per tile, loads return in order).  110 KB of LDS: the kernel runs one workgroup per
   // CU anyway (12 waves).
-  constexpr int NBUF = (DMA && KS == 5) ? 3 : 2;
+  constexpr int NBUF = (DMA && KS == 5 && TH == 4) ? 3 : 2;
   static_assert(NBUF == 2 || (NBUF == 3 && NPIECE % NWV == 0 && PPW <= 15), "counted vmcnt needs the same piece count in every wave");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * (XBYTES + GBYTES)];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -615,7 +622,8 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   if (k == 1 && ci % (32 * WC8_CIB1) != 0) return false;
   if (k == 3 && ci % (32 * Wc8Cit<3>::value) != 0) return false;
   pl->nchan_blocks = (co / 64) * (ci / (k == 1 ? 32 * WC8_CIB1 : k == 3 ? 32 * Wc8Cit<3>::value : 32));
-  const int tiles_y = (d->height + WC8_TH - 1) / WC8_TH;
+  const int th = k == 5 ? Wc8Th<5>::value : WC8_TH;
+  const int tiles_y = (d->height + th - 1) / th;
   int want = (WGRAD16_TARGET_BLOCKS + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);
   if (want < 1) want = 1;
   if (want > tiles_y) want = tiles_y;

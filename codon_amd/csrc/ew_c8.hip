@@ -348,7 +348,9 @@ int conv1ch_wgrad_c8(int B, int H, int W, const void* a, int a_ctotal, int a_cof
 // grid = (ntiles, B); a thread owns the 8 pixels tile0 + 256 k + tid and walks the 16 planes in Fcat order (colour
 // first): the per-pixel channel max / sum stay in two registers per pixel, the per-channel tile sums / maxima are
 // reduced in registers over the thread's pixels, then over the wave (shuffles), then over the 4 waves (LDS).
-template <class E>
+// NP = pixels per thread: NP (2048-pixel tiles), or 1 for small images (256-pixel tiles, all 16 planes' loads in flight:
+// cac.hip, STATS_SMALL_HW -- the tile rule is the fp32 pass's, so that codon_cac_stats_tiles holds for every dtype)
+template <class E, int NP = EW_NP>
 __global__ __launch_bounds__(256) void cac_stats_c8_kernel(C8Slice pre_c, C8Slice pre, float* __restrict__ pooled,
                                                            float* __restrict__ partials, long HW, int ntiles,
                                                            const float* __restrict__ chs) {
@@ -356,28 +358,29 @@ __global__ __launch_bounds__(256) void cac_stats_c8_kernel(C8Slice pre_c, C8Slic
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, b = blockIdx.y;
-  const long tile0 = (long)tile * EW_TILE;
+  const long tile0 = (long)tile * (256 * NP);
   const unsigned HW16 = 16u * (unsigned)HW;
-  bool ok[EW_NP];
-  unsigned vo[EW_NP];
+  bool ok[NP];
+  unsigned vo[NP];
 #pragma unroll
-  for (int k = 0; k < EW_NP; ++k) {
+  for (int k = 0; k < NP; ++k) {
     const long q = tile0 + k * 256 + tid;
     ok[k] = q < HW;
     vo[k] = ok[k] ? 16u * (unsigned)q : C8_OOB;
   }
-  float pmax[EW_NP], psum[EW_NP];
+  float pmax[NP], psum[NP];
 #pragma unroll
-  for (int k = 0; k < EW_NP; ++k) { pmax[k] = -INFINITY; psum[k] = 0.f; }
+  for (int k = 0; k < NP; ++k) { pmax[k] = -INFINITY; psum[k] = 0.f; }
   const __amdgpu_buffer_rsrc_t rc = c8_rsrc(pre_c, b, 8, HW16), rd = c8_rsrc(pre, b, 8, HW16);
 
-#pragma unroll 1
+  constexpr int PLU = NP == 1 ? 16 : 1;      // one pixel per thread: all 16 planes' loads in flight
+#pragma unroll PLU
   for (int pl = 0; pl < 16; ++pl) {
     const __amdgpu_buffer_rsrc_t r = pl < 8 ? rc : rd;
     const unsigned so = (unsigned)(pl & 7) * HW16;
-    u32x4 q[EW_NP];
+    u32x4 q[NP];
 #pragma unroll
-    for (int k = 0; k < EW_NP; ++k) q[k] = c8_ld(r, vo[k], so);
+    for (int k = 0; k < NP; ++k) q[k] = c8_ld(r, vo[k], so);
     float g8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g8[j] = chs ? chs[b * 64 + (pl & 7) * 8 + j] : 1.f;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256) void cac_stats_c8_kernel(C8Slice pre_c, C8Slic
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s8[j] = 0.f; m8[j] = -INFINITY; }
 #pragma unroll
-    for (int k = 0; k < EW_NP; ++k) {
+    for (int k = 0; k < NP; ++k) {
       float v[8];
       c8_unpack<E>(q[k], v);
 #pragma unroll
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256) void cac_stats_c8_kernel(C8Slice pre_c, C8Slic
   // per-pixel outputs: plane 0 = channel max, plane 1 = channel mean (max FIRST, CAC_module.py:81)
   float* pm = pooled + (long)b * 2 * HW;
 #pragma unroll
-  for (int k = 0; k < EW_NP; ++k) {
+  for (int k = 0; k < NP; ++k) {
     if (ok[k]) {
       const long q = tile0 + k * 256 + tid;
       pm[q] = pmax[k];
@@ -422,14 +425,24 @@ __global__ __launch_bounds__(256) void cac_stats_c8_kernel(C8Slice pre_c, C8Slic
   }
 }
 
+int cac_stats_tiles(int H, int W);          // cac.hip
 int cac_stats_fwd_c8(int B, int H, int W, const codon_tensor* pc, const codon_tensor* pd, float* pooled, float* partials,
                      int dtype, hipStream_t stream, const float* chs) {
   const long HW = (long)H * W;
-  const int nt = (int)((HW + EW_TILE - 1) / EW_TILE);
+  const int nt = cac_stats_tiles(H, W);
   CODON_REQUIRE(B <= 65535, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: batch %d > 65535", B);
   CODON_REQUIRE(c8_slice_ok(pc->ctotal, pc->coff, 64) && c8_slice_ok(pd->ctotal, pd->coff, 64), CODON_ERR_BAD_ARG,
                 "cac_stats_fwd: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
   CODON_REQUIRE(HW * 2 * 64 < (long)C8_OOB, CODON_ERR_UNSUPPORTED, "cac_stats_fwd: image too large for 32-bit buffer offsets");
+  if (nt != (int)((HW + EW_TILE - 1) / EW_TILE)) {          // small image: 256-pixel tiles (cac.hip)
+    if (dtype == CODON_F16)
+      hipLaunchKernelGGL((cac_stats_c8_kernel<C8F16, 1>), dim3(nt, B), dim3(256), 0, stream, c8_mk(pc, HW), c8_mk(pd, HW), pooled,
+                         partials, HW, nt, chs);
+    else
+      hipLaunchKernelGGL((cac_stats_c8_kernel<C8Bf16, 1>), dim3(nt, B), dim3(256), 0, stream, c8_mk(pc, HW), c8_mk(pd, HW), pooled,
+                         partials, HW, nt, chs);
+    return check_launch("cac_stats_c8_kernel<small>");
+  }
   if (dtype == CODON_F16)
     hipLaunchKernelGGL(cac_stats_c8_kernel<C8F16>, dim3(nt, B), dim3(256), 0, stream, c8_mk(pc, HW), c8_mk(pd, HW), pooled,
                        partials, HW, nt, chs);

@@ -42,6 +42,9 @@ TWO_STREAMS_MAX16 = int(_os.environ.get("CODON_TWO_STREAMS_MAX16", "256"))
 # ... and up to this many tiles the two streams of a block leave as PAIR launches (ops.conv_pair: one grid of twice the tiles
 # instead of two launches on two HIP streams -- no fork / join events, the second stream fills the first one's last round)
 PAIR_MAX16 = int(_os.environ.get("CODON_PAIR_MAX16", "4096"))
+# fp32: the pair form exists for the small-grid kernels (fewer than 384 tiles of 8 x 32 pixels, conv_mfma_f32.hip), where it
+# replaces the two-stream schedule; 0 = two streams (A/B)
+PAIR_MAX32 = int(_os.environ.get("CODON_PAIR_MAX32", "383"))
 # the whole gate of a block -- pool finish, MLP, spatial conv -- in one launch (codon_cac_tail_fwd); 0 = three / four launches (A/B)
 CAC_TAIL = _os.environ.get("CODON_CAC_TAIL", "1") != "0"
 _HALF_STREAMS: Dict[tuple, tuple] = {}
@@ -393,14 +396,22 @@ class _CODONBase(nn.Module):
         return self
 
     def _act_dtype(self) -> torch.dtype:
-        dt = self.compute_dtype or self.input.weight.dtype
+        dt = self.__dict__.get("compute_dtype")
+        if dt is None:
+            w = self._modules["input"]._parameters.get("weight")
+            dt = (w if w is not None else self._modules["input"].weight).dtype
         if dt not in (torch.float32, torch.bfloat16, torch.float16):
             raise NotImplementedError(f"codon_amd.CODONNet: dtype {dt} not supported (fp32, bf16, fp16)")
         return dt
 
     # -- packed weights -------------------------------------------------------------------
     def _packed(self, name: str, mode: int = L.PACK_FWD) -> torch.Tensor:
-        w = getattr(self, name).weight
+        # (nn.Module.__getattr__ twice per lookup is 1 us, 56 lookups a forward; nn.DataParallel replicas keep their
+        # tensors as plain attributes, not in _parameters)
+        mod = self._modules[name]
+        w = mod._parameters.get("weight")
+        if w is None:
+            w = mod.weight
         adt = self._act_dtype()
         if mode == L.PACK_FWD and self._split(w.shape[-1]):
             mode = L.PACK_FWD_F16X3
@@ -591,8 +602,11 @@ class _CODONBase(nn.Module):
         in2 = new(128)
         t64 = new(64)
         ops.stem(x, w_in, Slice(t64))
-        # 16-bit inference on a grid of at most PAIR_MAX16 tiles: the depth and the colour conv of every stage as ONE launch
-        pairs = ops.is_c8(adt) and (not keep) and B * ((H + 7) // 8) * ((W + 31) // 32) <= PAIR_MAX16
+        # inference on a small grid (16-bit: at most PAIR_MAX16 tiles; fp32: the small-grid kernels): the depth and the colour
+        # conv of every stage as ONE launch
+        # (not while bench.py brackets individual conv launches with HIP events: a held launch has no duration of its own)
+        pairs = (not keep) and ops.PROFILE is None and \
+            B * ((H + 7) // 8) * ((W + 31) // 32) <= (PAIR_MAX16 if ops.is_c8(adt) else min(PAIR_MAX32, 383))
         pair = lambda: ops.conv_pair(dev, pairs)
         t64c = new(64) if (keep or pairs) else t64
         if pairs:
@@ -642,7 +656,10 @@ class _CODONBase(nn.Module):
 
         nt = ops.cac_fused_tiles(H, W) if fused_stats else ops.cac_stats_tiles(H, W)
         fz = dict(dtype=torch.float32, device=dev)
-        tail = CAC_TAIL and (fused_stats or nt <= L.CAC_FOLDS)     # fp32: identical sums only while every fold holds one tile
+        # fp32: the one-launch gate folds the tiles before it finishes the pools -- the serial order of cac_gate_kernel while every
+        # fold holds one tile (nt <= 16), and the ONLY sensible form for the many small tiles of a small image (H W <= 32768:
+        # 256-pixel tiles, cac.hip), where a serial walk would take longer than the pass itself
+        tail = CAC_TAIL and (fused_stats or nt <= L.CAC_FOLDS or H * W <= 32768)
         if fused_stats:
             pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
         if fused_stats or tail:
@@ -681,8 +698,10 @@ class _CODONBase(nn.Module):
                     gconv(gate, gpre_c, inputs_c, out_c, "conv5", Slice(stage_c, 64, 64), 3, emitted=xg_c)
                     gconv(gate, gpre, inputs, out, "conv1", Slice(stage, 0, 64), 3, emitted=xg_d)
                 with pair():
-                    conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c, stats=(pool_c, partials, 0))
-                    conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre, stats=(pool_d, partials, 64))
+                    conv5_1x1(Slice(stage_c), "conv6", "confuse_c", Slice(r2_c), pre_c,
+                              stats=(pool_c, partials, 0) if fused_stats else None)
+                    conv5_1x1(Slice(stage), "conv3", "confuse", Slice(r2), pre,
+                              stats=(pool_d, partials, 64) if fused_stats else None)
             with _on_half(1):
                 if not pairs:
                     gconv(gate, gpre_c, inputs_c, out_c, "conv4", Slice(stage_c, 0, 64), 5, emit=xg_c)

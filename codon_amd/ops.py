@@ -40,7 +40,27 @@ def _dev(*ts):
 
 
 def _stream(dev) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    # the raw handle of torch's current stream on `dev` (torch.cuda.current_stream(dev).cuda_stream builds a Stream object and
+    # resolves the device three times: 4 us per launch of an eager one-image forward)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(dev):
+    """`with _on(dev):` = torch.cuda.device(dev), or nothing at all when `dev` already is the current device (the usual case:
+    the context manager costs 3-4 us per launch, which at one small image per call is the forward's host time)."""
+    i = dev.index
+    return _NULL if (i is None or i == torch.cuda.current_device()) else torch.cuda.device(dev)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -126,7 +146,7 @@ def packed_weight(w: torch.Tensor, mode: int = L.PACK_FWD, dtype: Optional[torch
     cout, cin, k, _ = w.shape
     dtype = dtype or torch.float32
     out = torch.empty(w.numel(), dtype=dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_conv_pack_weight(_ptr(w), _ptr(out), cout, cin, k, mode, _DT_CODE[dtype], _stream(dev)),
                 "conv_pack_weight")
     return out
@@ -147,7 +167,7 @@ class conv_pair:
     def __exit__(self, et, ev, tb):
         if not self.enabled:
             return False
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             n = L.load().codon_conv_pair_end(_stream(self.dev))
         if n < 0 and et is None:
             L.check(n, "conv_pair_end")
@@ -181,7 +201,7 @@ def conv2d(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, relu: bool = 
     if residual is not None:
         assert residual.c == y.c and _bhw(residual.buf) == (B, H, W)
     prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
@@ -206,7 +226,7 @@ def conv2d_sum_into(x: Slice, w_packed: torch.Tensor, y: Slice, ksize: int, tota
     d = L.ConvDesc(B, H, W, x.c, y.c, ksize, x.ctotal, x.coff, y.ctotal, y.coff, total.ctotal, total.coff,
                    L.CONV_ACCUM_OUT if accumulate else 0, _dt(x.buf))
     prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (ksize, x.c, y.c)) else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
@@ -234,7 +254,7 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
     d = L.ConvDesc(B, H, W, x.c, 128, 5, x.ctotal, x.coff, mid.ctotal if mid else 128, mid.coff if mid else 0,
                    0, 0, flags, _dt(x.buf))
     prof = PROFILE if (PROFILE is not None and PROFILE["key"] == (5, x.c, 128)) else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
@@ -270,7 +290,7 @@ def conv2d_gated(pre: Slice, inputs: Slice, ch: torch.Tensor, sp: torch.Tensor, 
     d = L.ConvDesc(B, H, W, pre.c, y.c, ksize, pre.ctotal, pre.coff, y.ctotal, y.coff, 0, 0,
                    L.CONV_RELU if relu else 0, _dt(pre.buf))
     it = inputs.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         if emit is not None:
             assert emit.c == pre.c and _bhw(emit.buf) == (B, H, W) and emit.buf.dtype == pre.buf.dtype
             et = emit.ct()
@@ -337,7 +357,7 @@ class DeferredReduce:
         if not rounds[0]:
             return
         dev = _dev(*[outs[k] for k in self.keys()])
-        with torch.cuda.device(dev):
+        with _on(dev):
             for items in rounds:
                 arr = (L.ReduceItem * len(items))(*items)
                 L.check(L.load().codon_reduce_multi(arr, len(items), _stream(dev)), "reduce_multi")
@@ -357,7 +377,7 @@ def conv2d_wgrad(x: Slice, gy: Slice, dw: Optional[torch.Tensor], ksize: int, ac
         raise RuntimeError(f"codon_amd: no wgrad kernel for k={ksize} cin={x.c} cout={gy.c}")
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     prof = PROFILE if (PROFILE is not None and PROFILE.get("wgrad_key") == (ksize, x.c, gy.c)) else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
@@ -387,7 +407,7 @@ def conv1x1_bwd(x: Slice, gy: Slice, w_packed_dgrad: torch.Tensor, gx: Slice, dw
         raise RuntimeError(f"codon_amd: no wgrad kernel for k=1 cin={x.c} cout={gy.c}")
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     gt = gx.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         mode = L.WGRAD_DEFER if defer is not None else (1 if accumulate else 0)
         L.check(lib.codon_conv1x1_bwd(C.byref(d), _ptr(x.buf), _ptr(gy.buf), _ptr(w_packed_dgrad), C.byref(gt),
                                       None if defer is not None else _ptr(dw), _ptr(ws), nbytes, mode, _stream(dev)),
@@ -401,7 +421,7 @@ def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
     dev = _dev(x, w, y.buf)
     B, _, H, W = x.shape
     assert y.c == 64 and x.dtype == torch.float32 and w.dtype == torch.float32
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_stem_fwd(B, H, W, _ptr(x), _ptr(w), _ptr(y.buf), y.ctotal, y.coff, _dt(y.buf),
                                    _stream(dev)), "stem_fwd")
 
@@ -411,7 +431,7 @@ def head(x: Slice, w: torch.Tensor, residual: torch.Tensor, y: torch.Tensor):
     dev = _dev(x.buf, w, residual, y)
     B, H, W = _bhw(x.buf)
     assert x.c == 64 and w.dtype == torch.float32 and residual.dtype == torch.float32 and y.dtype == torch.float32
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_head_fwd(B, H, W, _ptr(x.buf), x.ctotal, x.coff, _ptr(w), _ptr(residual), _ptr(y),
                                    _dt(x.buf), _stream(dev)), "head_fwd")
 
@@ -441,7 +461,7 @@ def params_f32(tensors):
             t = tensors[i]
             d.src[j], d.count[j], d.dtype[j] = t.data_ptr(), t.numel(), _dt(t)
         flat = torch.empty(sum(tensors[i].numel() for i in idx), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             L.check(lib.codon_cast_multi(C.byref(d), _ptr(flat), _stream(dev)), "cast_multi")
         off = 0
         for i in idx:
@@ -459,7 +479,7 @@ def cac_tail(B: int, H: int, W: int, partials, pool_c, pool_d, pooled, folded, c
     dev = _dev(partials, pool_c, pool_d, pooled, folded, counters, w1, b1, w2, b2, ws, ch, sp, pools_out)
     assert tuple(folded.shape) == (B, L.CAC_FOLDS, 128, 2) and counters.dtype == torch.int32 and counters.numel() >= B
     assert partials.shape[0] == B and tuple(partials.shape[2:]) == (128, 2)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_tail_fwd(B, H, W, int(partials.shape[1]), _ptr(partials), _ptr(pool_c), _ptr(pool_d), _ptr(pooled),
                                        _ptr(folded), _ptr(counters), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ws), _ptr(ch),
                                        _ptr(pools_out), _ptr(sp), _stream(dev)), "cac_tail_fwd")
@@ -471,7 +491,7 @@ def cac_fused_finish(B: int, H: int, W: int, partials, pool_c, pool_d, folded, p
     lib = L.load()
     dev = _dev(partials, pool_c, pool_d, folded, pooled)
     assert tuple(folded.shape) == (B, L.CAC_FOLDS, 128, 2) and tuple(pooled.shape) == (B, 2, H, W)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_fused_finish(B, H, W, _ptr(partials), _ptr(pool_c), _ptr(pool_d), _ptr(folded), _ptr(pooled),
                                            _stream(dev)), "cac_fused_finish")
 
@@ -479,7 +499,7 @@ def cac_fused_finish(B: int, H: int, W: int, partials, pool_c, pool_d, folded, p
 def cac_gate_folded(B: int, H: int, W: int, folded, w1, b1, w2, b2, ch, pools_out=None):
     lib = L.load()
     dev = _dev(folded, w1, b1, w2, b2, ch, pools_out)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_gate_folded_fwd(B, H, W, _ptr(folded), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ch),
                                               _ptr(pools_out), _stream(dev)), "cac_gate_folded_fwd")
 
@@ -489,7 +509,7 @@ def cac_stats(pre_c: Slice, pre: Slice, pooled: torch.Tensor, partials: torch.Te
     dev = _dev(pre_c.buf, pre.buf, pooled, partials)
     B, H, W = _bhw(pre.buf)
     a, b = pre_c.ct(), pre.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_stats_fwd(B, H, W, C.byref(a), C.byref(b), _ptr(pooled), _ptr(partials),
                                         _dt(pre.buf), _stream(dev)), "cac_stats_fwd")
 
@@ -501,7 +521,7 @@ def cac_stats_scaled(pre_c: Slice, pre: Slice, ch: torch.Tensor, pooled: torch.T
     B, H, W = _bhw(pre.buf)
     assert ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
     a, b = pre_c.ct(), pre.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_stats_scaled_fwd(B, H, W, C.byref(a), C.byref(b), _ptr(ch), _ptr(pooled), _ptr(partials),
                                                _dt(pre.buf), _stream(dev)), "cac_stats_scaled_fwd")
 
@@ -513,7 +533,7 @@ def ew_sq_scale(x: Slice, ch: torch.Tensor, y: Slice):
     B, H, W = _bhw(x.buf)
     assert x.c == 64 and y.c == 64 and ch.dtype == torch.float32 and tuple(ch.shape) == (B, 64)
     xt, yt = x.ct(), y.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_ew_sq_scale(B, H, W, C.byref(xt), _ptr(ch), C.byref(yt), _dt(x.buf), _stream(dev)), "ew_sq_scale")
 
 
@@ -522,7 +542,7 @@ def cac_gate(B: int, H: int, W: int, partials, w1, b1, w2, b2, ch, pools_out=Non
     dev = _dev(partials, w1, b1, w2, b2, ch, pools_out)
     for t in (w1, b1, w2, b2):
         assert t.dtype == torch.float32
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_gate_fwd(B, H, W, _ptr(partials), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ch),
                                        _ptr(pools_out), _stream(dev)), "cac_gate_fwd")
 
@@ -532,7 +552,7 @@ def cac_spatial(pooled: torch.Tensor, w: torch.Tensor, sp: torch.Tensor):
     dev = _dev(pooled, w, sp)
     B, _, H, W = pooled.shape
     assert w.dtype == torch.float32
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_spatial_fwd(B, H, W, _ptr(pooled), _ptr(w), _ptr(sp), _stream(dev)),
                 "cac_spatial_fwd")
 
@@ -542,7 +562,7 @@ def cac_apply(pre: Slice, pre_c: Slice, ch, sp, inputs: Slice, inputs_c: Slice, 
     dev = _dev(pre.buf, pre_c.buf, ch, sp, inputs.buf, inputs_c.buf, out.buf, out_c.buf)
     B, H, W = _bhw(pre.buf)
     ts = [s.ct() for s in (pre, pre_c, inputs, inputs_c, out, out_c)]
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_apply_fwd(B, H, W, C.byref(ts[0]), C.byref(ts[1]), _ptr(ch), _ptr(sp),
                                         C.byref(ts[2]), C.byref(ts[3]), C.byref(ts[4]), C.byref(ts[5]),
                                         _dt(pre.buf), _stream(dev)), "cac_apply_fwd")
@@ -558,7 +578,7 @@ def stencil_1to64(x: torch.Tensor, w: torch.Tensor, y: Slice, relu: bool = False
     assert y.c == 64 and w.numel() == 576 and w.dtype == torch.float32 and x.dtype == torch.float32
     yt = y.ct()
     mt = mask.ct() if mask is not None else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_stencil_1to64(B, H, W, _ptr(x), _ptr(w), C.byref(yt), (1 if relu else 0) | (2 if flip else 0),
                                         C.byref(mt) if mt is not None else None, _dt(y.buf), _stream(dev)),
                 "stencil_1to64")
@@ -574,7 +594,7 @@ def conv1ch_wgrad(a: Slice, s: torch.Tensor, dw: Optional[torch.Tensor], flip: b
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     at = a.ct()
     flags = (L.W1_FLIP if flip else 0) | (L.W1_ACCUMULATE if accumulate else 0) | (L.W1_DEFER if defer is not None else 0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_conv1ch_wgrad(B, H, W, C.byref(at), _ptr(s), None if defer is not None else _ptr(dw), flags,
                                         _ptr(ws), nbytes, _dt(a.buf), _stream(dev)), "conv1ch_wgrad")
     if defer is not None:
@@ -586,7 +606,7 @@ def ew_add_mask(dst: Slice, src: Optional[Slice] = None, mask: Optional[Slice] =
     dev = _dev(dst.buf, src.buf if src else None, mask.buf if mask else None)
     B, H, W = _bhw(dst.buf)
     dt_, st_, mt_ = dst.ct(), (src.ct() if src else None), (mask.ct() if mask else None)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_ew_add_mask(B, H, W, dst.c, C.byref(dt_), C.byref(st_) if st_ is not None else None,
                                       C.byref(mt_) if mt_ is not None else None, 1 if accumulate else 0,
                                       _dt(dst.buf), _stream(dev)), "ew_add_mask")
@@ -603,7 +623,7 @@ def ew_sum_mask(dst: Slice, srcs, mask: Optional[Slice] = None):
     dt_, mt_ = dst.ct(), (mask.ct() if mask else None)
     sts = [s_.ct() for s_ in srcs]
     args = [C.byref(t) for t in sts] + [None] * (4 - len(sts))
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_ew_sum_mask(B, H, W, dst.c, C.byref(dt_), len(sts), *args,
                                       C.byref(mt_) if mt_ is not None else None, _dt(dst.buf), _stream(dev)), "ew_sum_mask")
 
@@ -643,7 +663,7 @@ def cac_backward(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, ch, sp,
     dw1, db1, dw2, db2, dws = _cac_param_outputs(defer, B, nsb, part_param, part_w, f32)
     t = [s.ct() for s in (g_out, g_out_c, pre, pre_c, g_pre, g_pre_c, g_in, g_in_c)]
     st = _stream(dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_bwd_reduce(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]),
                                          _ptr(ch), _ptr(sp), _ptr(pools), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
                                          _dt(pre.buf), st), "cac_bwd_reduce")
@@ -685,7 +705,7 @@ def cac_backward_fused(g_out: Slice, g_out_c: Slice, pre: Slice, pre_c: Slice, c
     dw1, db1, dw2, db2, dws = _cac_param_outputs(defer, B, nsb, part_param, part_w, f32)
     t = [s_.ct() for s_ in (g_out, g_out_c, pre, pre_c, g_in, g_in_c)]
     st = _stream(dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         L.check(lib.codon_cac_bwd_reduce_acc(B, H, W, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(t[3]), _ptr(ch),
                                              _ptr(sp), _ptr(pools), _ptr(pooled), _ptr(g_z), _ptr(part_gch), _ptr(part_arg),
                                              _ptr(argch), C.byref(t[4]), C.byref(t[5]), int(accumulate_in),
@@ -716,7 +736,7 @@ def conv1x1_bwd_gated(x: Slice, g_out: Slice, w_packed_dgrad: torch.Tensor, gx: 
         raise RuntimeError(f"codon_amd: no wgrad kernel for k=1 cin={x.c} cout={g_out.c}")
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     gt = gx.ct()
-    with torch.cuda.device(dev):
+    with _on(dev):
         mode = L.WGRAD_DEFER if defer is not None else (1 if accumulate else 0)
         L.check(lib.codon_conv1x1_bwd_gated(C.byref(d), _ptr(x.buf), _ptr(g_out.buf), _ptr(w_packed_dgrad), C.byref(gt),
                                             None if defer is not None else _ptr(dw), _ptr(ws), nbytes, mode, _ptr(gate["ch"]),

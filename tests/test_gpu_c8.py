@@ -827,18 +827,25 @@ def test_forward_with_one_launch_gate_and_two_streams_is_bit_identical(mode):
     y = torch.rand((1, 1, H, W), device=dev)
     if mode == "fp16":
         x, y = x.half(), y.half()
-    old = (M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16)
-    outs = []
+    old = (M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16, M.PAIR_MAX32)
+    outs = {False: [], True: []}
     try:
         for tail, m16, m32, pr in ((False, 0, 0, 0), (True, 0, 0, 0), (True, 4096, 4096, 0), (False, 4096, 4096, 0),
                                    (True, 0, 0, 4096), (False, 4096, 4096, 4096)):
-            M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16 = tail, m16, m32, pr
+            M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16, M.PAIR_MAX32 = tail, m16, m32, pr, pr
             with torch.no_grad():
-                outs.append(net(x, y).clone())
+                outs[tail].append(net(x, y).clone())
             torch.cuda.synchronize()
     finally:
-        M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16 = old
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+        M.CAC_TAIL, M.TWO_STREAMS_MAX16, M.TWO_STREAMS_MAX32, M.PAIR_MAX16, M.PAIR_MAX32 = old
+    for grp in outs.values():
+        assert all(torch.equal(grp[0], o) for o in grp[1:])
+    if mode == "fp32":
+        # 24 small statistics tiles: the one-launch gate folds them in pairs before finishing the pools, the separate gate
+        # kernel adds them one by one -- fp32 re-association of a 24-term sum, nothing else
+        assert rel_rmse(outs[True][0].float().cpu(), outs[False][0].float().cpu()) < 2e-5     # (measured 1.5e-6)
+    else:
+        assert torch.equal(outs[True][0], outs[False][0])
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -901,3 +908,51 @@ def test_conv_pair_is_one_launch_and_bit_identical(dtype):
     with ops.conv_pair(dev):
         with pytest.raises(RuntimeError, match="already inside a pair"):
             L.check(L.load().codon_conv_pair_begin(), "conv_pair_begin")
+
+
+def test_conv_pair_fp32_small_grid():
+    """fp32: the pair form exists for the small-grid kernels (one 64 x 96 image = 96 tiles): one launch, same bits -- plain,
+    chained 1x1 and gated + emitting; a large grid launches at once (two launches)."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = 1, 64, 96
+    q = lambda c, seed: _rand((B, c, H, W), seed).to(dev)
+    xa, xb = q(128, 1), q(128, 2)
+    wt = lambda co, ci, k, seed, mode=L.PACK_FWD: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), mode, torch.float32)
+    w5a, w5b, w3a, w3b, w5 = wt(64, 64, 5, 3), wt(64, 64, 5, 4), wt(64, 64, 3, 5), wt(64, 64, 3, 6), wt(128, 128, 5, 7)
+    w1 = wt(64, 128, 1, 8, L.PACK_CHAIN1X1)
+    ch, sp = torch.rand((B, 64), device=dev), torch.rand((B, 1, H, W), device=dev)
+
+    def run(paired):
+        o = [torch.zeros((B, 128, H, W), device=dev) for _ in range(5)]
+        ns = []
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d(Slice(xa, 0, 64), w5a, Slice(o[0], 64, 64), 5, relu=True)
+            ops.conv2d(Slice(xb, 64, 64), w5b, Slice(o[0], 0, 64), 5, relu=True)
+        ns.append(pr.launches)
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d(Slice(xa, 64, 64), w3a, Slice(o[1], 0, 64), 3, relu=True)
+            ops.conv2d(Slice(xb, 0, 64), w3b, Slice(o[1], 64, 64), 3, relu=True)
+        ns.append(pr.launches)
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv_chain1x1(Slice(xa), w5, w1, Slice(o[2], 64, 64))
+            ops.conv_chain1x1(Slice(xb), w5, w1, Slice(o[2], 0, 64))
+        ns.append(pr.launches)
+        with ops.conv_pair(dev, paired) as pr:
+            ops.conv2d_gated(Slice(o[2], 64, 64), Slice(xa, 64, 64), ch, sp, w5a, Slice(o[3], 0, 64), 5, relu=True, emit=Slice(o[4], 64, 64))
+            ops.conv2d_gated(Slice(o[2], 0, 64), Slice(xa, 0, 64), ch, sp, w5b, Slice(o[3], 64, 64), 5, relu=True, emit=Slice(o[4], 0, 64))
+        ns.append(pr.launches)
+        return o, ns
+
+    o0, _ = run(False)
+    o1, ns = run(True)
+    assert ns == [1, 1, 1, 1], ns
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1))
+    big_x = _rand((4, 128, 96, 128), 9).to(dev)           # 4 x 12 x 4 = 192... x 2 rows: a LARGE grid (>= 384 tiles of 8 x 32)
+    big_x = _rand((8, 128, 96, 128), 9).to(dev)
+    yb = torch.zeros((8, 128, 96, 128), device=dev)
+    with ops.conv_pair(dev) as pr:
+        ops.conv2d(Slice(big_x, 0, 64), w5a, Slice(yb, 0, 64), 5)
+        ops.conv2d(Slice(big_x, 64, 64), w5b, Slice(yb, 64, 64), 5)
+    assert pr.launches == 0                # both launched at once, nothing was held
