@@ -26,13 +26,18 @@
 namespace codon {
 
 constexpr int WC8_TH = 4;
-// k = 5, round 5 A/B: rows of a staged tile.  8 = the x halo is 12 rows for 8 (1.5x) instead of 8 for 4 (2x) -- the HBM / L2 traffic
-// of the launch falls from ~1.5x to ~1.25x its algorithmic bytes -- in TWO buffers of twice the size (122 KB of LDS): the DMA of tile
-// t+2 still has two 4-row tile times to land, and there are half as many publishing barriers
+// k = 5 (round 5): a staged tile is 8 rows x 32 pixels.  Its x halo is 12 rows for 8 (1.5x) instead of 8 for 4 (2x): the HBM
+// traffic of a 128 -> 128 launch fell from 7.60 to 6.34 GB (1.51x -> 1.26x its 5.03 GB algorithmic bytes, PMC), 5.92 -> 5.72 ms
+// stand-alone, matrix pipe 75 -> 79 % busy at 1.71 -> 1.67 GHz (the kernel runs at the socket's power cap: bytes not moved come
+// back as issue slots).  TWO buffers of twice the size (122 KB of LDS) instead of three: the DMA of tile t+2 still has two
+// 4-row tile times to land, and there are half as many publishing barriers.  (4 rows with three buffers: -DCODON_WC8_TH5=4.)
 #ifndef CODON_WC8_TH5
-#define CODON_WC8_TH5 4
+#define CODON_WC8_TH5 8
 #endif
-template <int KS> struct Wc8Th { static constexpr int value = KS == 5 ? CODON_WC8_TH5 : WC8_TH; };
+#ifndef CODON_WC8_TH3
+#define CODON_WC8_TH3 6          // k = 3 (round 5): an 8-row halo for 6 rows (1.33x) instead of 6 for 4 (1.5x), 125 KB of LDS: 0.74 -> 0.72 ms; 4 = A/B
+#endif
+template <int KS> struct Wc8Th { static constexpr int value = KS == 5 ? CODON_WC8_TH5 : KS == 3 ? CODON_WC8_TH3 : WC8_TH; };
 constexpr int WC8_CIB1 = 4;          // k = 1: 128 cin per workgroup
 // k = 3: cin tiles per workgroup, each with its own 2*KS waves: 2 -> 64 cout x 64 cin, 12 waves = 3 per SIMD (balanced),
 // twice the MFMAs per staged byte and per barrier
@@ -622,7 +627,7 @@ static bool wgrad16_plan(const codon_conv_desc* d, Wgrad16Plan* pl) {
   if (k == 1 && ci % (32 * WC8_CIB1) != 0) return false;
   if (k == 3 && ci % (32 * Wc8Cit<3>::value) != 0) return false;
   pl->nchan_blocks = (co / 64) * (ci / (k == 1 ? 32 * WC8_CIB1 : k == 3 ? 32 * Wc8Cit<3>::value : 32));
-  const int th = k == 5 ? Wc8Th<5>::value : WC8_TH;
+  const int th = k == 5 ? Wc8Th<5>::value : k == 3 ? Wc8Th<3>::value : WC8_TH;
   const int tiles_y = (d->height + th - 1) / th;
   int want = (WGRAD16_TARGET_BLOCKS + pl->nchan_blocks * d->batch - 1) / (pl->nchan_blocks * d->batch);
   if (want < 1) want = 1;
