@@ -152,11 +152,26 @@ __global__ __launch_bounds__(256) void cac_spatial_kernel(const float* __restric
   const int x0 = tx * SPF_T, y0 = ty * SPF_T;
   const long HW = (long)H * W;
   const float* base = pooled + (long)b * 2 * HW;
-  for (int e = tid; e < 2 * SPF_HALO * SPF_HALO; e += 256) {
-    const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
-    const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
-    const int yy = y0 + r - 2, xx = x0 + q - 2;
-    tl[c][r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[c * HW + (long)yy * W + xx] : 0.f;
+  {  // two phases, fully unrolled: all loads of the halo tile in flight before the first use (see cac_tail_kernel)
+    constexpr int NE = (2 * SPF_HALO * SPF_HALO + 255) / 256;
+    float vv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = min(tid + k * 256, 2 * SPF_HALO * SPF_HALO - 1);
+      const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
+      const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
+      const int yy = min(max(y0 + r - 2, 0), H - 1), xx = min(max(x0 + q - 2, 0), W - 1);
+      vv[k] = base[c * HW + (long)yy * W + xx];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = tid + k * 256;
+      if (e >= 2 * SPF_HALO * SPF_HALO) break;
+      const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
+      const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
+      const int yy = y0 + r - 2, xx = x0 + q - 2;
+      tl[c][r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? vv[k] : 0.f;
+    }
   }
   __syncthreads();
   const int cx = tid & 31, r0 = (tid >> 5) * 4;
@@ -231,25 +246,6 @@ static bool stats_small(long HW) { return HW <= STATS_SMALL_HW; }
 int cac_stats_tiles(int H, int W) {
   const long HW = (long)H * W;
   return stats_small(HW) ? (int)((HW + STATS_SMALL_TILE - 1) / STATS_SMALL_TILE) : (int)((HW + STATS_TILE - 1) / STATS_TILE);
-}
-
-// Wave-wide sum / max by DPP (row rotations inside the 16-lane rows, then the two row broadcasts): six VALU instructions, the
-// result in LANE 63.  __shfl_xor goes through ds_bpermute -- 1536 dependent LDS-crossbar round trips per thread for the 128
-// channels of a pixel took 25 of this kernel's 37 us.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_take(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-template <bool MAX>
-__device__ __forceinline__ float wave_red63(float v) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-  v = op(v, dpp_take<0xB1>(v));            // quad_perm [1,0,3,2]
-  v = op(v, dpp_take<0x4E>(v));            // quad_perm [2,3,0,1]
-  v = op(v, dpp_take<0x124>(v));           // row_ror:4
-  v = op(v, dpp_take<0x128>(v));           // row_ror:8   -> every lane holds its row's result
-  v = op(v, dpp_take<0x142, 0xa>(v));      // row_bcast:15 into rows 1, 3
-  v = op(v, dpp_take<0x143, 0xc>(v));      // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's
-  return v;
 }
 
 // grid = (ntiles, B), 256 threads, thread = pixel.  Same outputs as cac_stats_kernel (per-pixel channel max / mean, per-tile
@@ -409,18 +405,37 @@ __global__ __launch_bounds__(256) void cac_tail_kernel(const CacTailArgs a) {
     const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
     const int x0 = tx * SPF_T, y0 = ty * SPF_T;
     const long ib = (long)b * 2 * HW;
-    for (int e = tid; e < 2 * SPF_HALO * SPF_HALO; e += 256) {
+    // two phases, fully unrolled: every load of the halo tile is in flight before the first value is used or stored (a
+    // load / combine / store loop ran the tile's 11 rounds as 11 dependent memory round trips: 287 us per launch at
+    // 32 x 480 x 640 against 156 us for the four kernels this one replaces)
+    constexpr int NE = (2 * SPF_HALO * SPF_HALO + 255) / 256;
+    float va[NE], vb[NE];
+    long oo[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = tid + k * 256;
       const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
       const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
       const int yy = y0 + r - 2, xx = x0 + q - 2;
+      const bool in = e < 2 * SPF_HALO * SPF_HALO && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      oo[k] = in ? ib + c * HW + (long)yy * W + xx : -1;
+      const long o = in ? oo[k] : ib;                         // unconditional loads from a valid address, masked below
+      if (a.pool_c) { va[k] = a.pool_c[o]; vb[k] = a.pool_d[o]; }
+      else { va[k] = a.pooled_in[o]; vb[k] = 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = tid + k * 256;
+      if (e >= 2 * SPF_HALO * SPF_HALO) break;
+      const int c = e / (SPF_HALO * SPF_HALO), rem = e - c * (SPF_HALO * SPF_HALO);
+      const int r = rem / SPF_HALO, q = rem - r * SPF_HALO;
       float v = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const long o = ib + c * HW + (long)yy * W + xx;
+      if (oo[k] >= 0) {
         if (a.pool_c) {
-          v = c == 0 ? fmaxf(a.pool_c[o], a.pool_d[o]) : (a.pool_c[o] + a.pool_d[o]) * (1.f / 128.f);
-          if (a.pooled_out && r >= 2 && r < 2 + SPF_T && q >= 2 && q < 2 + SPF_T) a.pooled_out[o] = v;
+          v = c == 0 ? fmaxf(va[k], vb[k]) : (va[k] + vb[k]) * (1.f / 128.f);
+          if (a.pooled_out && r >= 2 && r < 2 + SPF_T && q >= 2 && q < 2 + SPF_T) a.pooled_out[oo[k]] = v;
         } else {
-          v = a.pooled_in[o];
+          v = va[k];
         }
       }
       tl[c][r][q] = v;

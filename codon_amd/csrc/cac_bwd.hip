@@ -243,13 +243,27 @@ __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __res
   const long HW = (long)H * W;
   const float* gz = g_z + (long)b * HW;
   const float* pl = pooled + (long)b * 2 * HW;
-  for (int e = tid; e < 3 * SPB_HALO * SPB_HALO; e += 256) {
+  // two phases, fully unrolled: every load of the three halo planes is in flight before the first value is used (`in ? load
+  // : 0` in a loop compiled to a branch and a full wait per round: 16 dependent memory round trips per workgroup)
+  constexpr int NE = (3 * SPB_HALO * SPB_HALO + 255) / 256;
+  float vv[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = min(tid + k * 256, 3 * SPB_HALO * SPB_HALO - 1);
+    const int c = e / (SPB_HALO * SPB_HALO), rem = e - c * (SPB_HALO * SPB_HALO);
+    const int r = rem / SPB_HALO, q = rem - r * SPB_HALO;
+    const int yy = min(max(y0 + r - 2, 0), H - 1), xx = min(max(x0 + q - 2, 0), W - 1);   // clamped: a valid address, masked below
+    const float* src = c == 0 ? gz : pl + (long)(c - 1) * HW;
+    vv[k] = src[(long)yy * W + xx];
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = tid + k * 256;
+    if (e >= 3 * SPB_HALO * SPB_HALO) break;
     const int c = e / (SPB_HALO * SPB_HALO), rem = e - c * (SPB_HALO * SPB_HALO);
     const int r = rem / SPB_HALO, q = rem - r * SPB_HALO;
     const int yy = y0 + r - 2, xx = x0 + q - 2;
-    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-    const float* src = c == 0 ? gz : pl + (long)(c - 1) * HW;
-    tl[c][r][q] = in ? src[(long)yy * W + xx] : 0.f;
+    tl[c][r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? vv[k] : 0.f;
   }
   __syncthreads();
   // a thread owns 4 consecutive rows of one column: the 8 x 5 window of a plane is read once for its 4 pixels
@@ -295,8 +309,8 @@ __global__ __launch_bounds__(256) void cac_bwd_spatial_kernel(const float* __res
   }
 #pragma unroll
   for (int t = 0; t < 25; ++t) {
-    const float p0 = wsum(a0[t]), p1 = wsum(a1[t]);
-    if (lane == 0) { red[t][wave] = p0; red[25 + t][wave] = p1; }
+    const float p0 = wave_red63<false>(a0[t]), p1 = wave_red63<false>(a1[t]);      // DPP: 6 VALU each, result in lane 63
+    if (lane == 63) { red[t][wave] = p0; red[25 + t][wave] = p1; }
   }
   __syncthreads();
   if (tid < 50) part_w[(long)blockIdx.x * 50 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);

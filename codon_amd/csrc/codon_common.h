@@ -50,6 +50,25 @@ inline long long* codon_dbg_ptr() {
 #define CODON_TSTAMP(dbg_, k_)
 #endif
 
+// Wave-wide sum / max by DPP (row rotations inside the 16-lane rows, then the two row broadcasts): six VALU instructions, the
+// result in LANE 63.  __shfl_xor goes through ds_bpermute -- 1536 dependent LDS-crossbar round trips per thread for the 128
+// channels of a pixel took 25 of this kernel's 37 us.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_red63(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, dpp_take<0xB1>(v));            // quad_perm [1,0,3,2]
+  v = op(v, dpp_take<0x4E>(v));            // quad_perm [2,3,0,1]
+  v = op(v, dpp_take<0x124>(v));           // row_ror:4
+  v = op(v, dpp_take<0x128>(v));           // row_ror:8   -> every lane holds its row's result
+  v = op(v, dpp_take<0x142, 0xa>(v));      // row_bcast:15 into rows 1, 3
+  v = op(v, dpp_take<0x143, 0xc>(v));      // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's
+  return v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -47,6 +47,7 @@ PAIR_MAX16 = int(_os.environ.get("CODON_PAIR_MAX16", "4096"))
 PAIR_MAX32 = int(_os.environ.get("CODON_PAIR_MAX32", "383"))
 # the whole gate of a block -- pool finish, MLP, spatial conv -- in one launch (codon_cac_tail_fwd); 0 = three / four launches (A/B)
 CAC_TAIL = _os.environ.get("CODON_CAC_TAIL", "1") != "0"
+CAC_TAIL_MAX_PIXELS = 1 << 21
 _HALF_STREAMS: Dict[tuple, tuple] = {}
 
 
@@ -659,7 +660,10 @@ class _CODONBase(nn.Module):
         # fp32: the one-launch gate folds the tiles before it finishes the pools -- the serial order of cac_gate_kernel while every
         # fold holds one tile (nt <= 16), and the ONLY sensible form for the many small tiles of a small image (H W <= 32768:
         # 256-pixel tiles, cac.hip), where a serial walk would take longer than the pass itself
-        tail = CAC_TAIL and (fused_stats or nt <= L.CAC_FOLDS or H * W <= 32768)
+        # 16-bit: bit-identical to the separate launches at any size, and FASTER only while the grid is small (12 vs 25 us for
+        # one 370 x 463 image; 210 vs 147 us at 32 x 480 x 640, where the combine inside the spatial tiles re-reads four maps'
+        # halos) -- so it is chosen by size there; fp32: by H x W only, so that an image's bits never depend on its batch
+        tail = CAC_TAIL and (B * H * W <= CAC_TAIL_MAX_PIXELS if fused_stats else (nt <= L.CAC_FOLDS or H * W <= 32768))
         if fused_stats:
             pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
         if fused_stats or tail:
