@@ -39,10 +39,10 @@ def _dev(*ts):
     return d
 
 
-def _stream(dev) -> C.c_void_p:
+def _stream(dev) -> int:
     # the raw handle of torch's current stream on `dev` (torch.cuda.current_stream(dev).cuda_stream builds a Stream object and
-    # resolves the device three times: 4 us per launch of an eager one-image forward)
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    # resolves the device three times: 4 us per launch of an eager one-image forward); ctypes takes the int for a void*
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 class _NullCtx:
@@ -64,7 +64,7 @@ def _on(dev):
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    return t.data_ptr() if t is not None else None        # ctypes converts int / None for a c_void_p argument
 
 
 # bench.py sets PROFILE = {"key": (ksize, cin, cout), "events": []} to bracket every launch of one conv
@@ -115,19 +115,22 @@ def _channels(buf: torch.Tensor) -> int:
 class Slice:
     """Channels [coff, coff+c) of an activation buffer: contiguous (B, ctotal, H, W) for fp32, channel-blocked
     (B, ctotal/8, H, W, 8) for bf16 / fp16 (then coff and c are multiples of 8)."""
-    __slots__ = ("buf", "coff", "c")
+    __slots__ = ("buf", "coff", "c", "ctotal")
 
     def __init__(self, buf: torch.Tensor, coff: int = 0, c: Optional[int] = None):
-        self.buf, self.coff = buf, coff
-        self.c = _channels(buf) - coff if c is None else c
-        assert 0 <= coff and coff + self.c <= _channels(buf)
-        assert buf.dim() == 4 or (buf.dim() == 5 and buf.shape[4] == 8 and is_c8(buf.dtype) and coff % 8 == 0
-                                  and self.c % 8 == 0)
-        assert buf.dim() == 5 or not is_c8(buf.dtype), "16-bit activations must be channel-blocked (ops.from_nchw)"
-
-    @property
-    def ctotal(self):
-        return _channels(self.buf)
+        sh = buf.shape
+        blocked = len(sh) == 5
+        ct = sh[1] * 8 if blocked else sh[1]
+        if c is None:
+            c = ct - coff
+        self.buf, self.coff, self.c, self.ctotal = buf, coff, c, ct
+        # (one combined test: ~115 slices are built per forward, and at one small image per call that is host time)
+        half = buf.dtype is torch.bfloat16 or buf.dtype is torch.float16
+        if coff < 0 or coff + c > ct or (blocked and (sh[4] != 8 or not half or (coff | c) & 7)) or \
+                (not blocked and (len(sh) != 4 or half)):
+            assert 0 <= coff and coff + c <= ct, "channel slice outside its buffer"
+            assert blocked or not half, "16-bit activations must be channel-blocked (ops.from_nchw)"
+            assert False, "a 16-bit slice is whole 8-channel planes of a (B, C/8, H, W, 8) buffer; fp32 buffers are (B, C, H, W)"
 
     def view(self):
         """The slice as a (B,c,H,W) tensor (a copy for the channel-blocked layout)."""
