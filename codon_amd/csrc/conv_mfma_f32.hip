@@ -106,17 +106,24 @@ enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 // the halo is 20 x 36 / (16 x 32) = 1.41x the tile instead of 1.69x, and the weight stage is staged once per CU).
 // The body takes the parameter block by reference and its (XCD-remapped) tile index as an argument: the same code serves the
 // one-conv launch and the pair launch (conv_mfma_f32_pair_kernel).
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+// CSPLIT (round 5, small grids only): the four waves of a workgroup are 2 pixel rows x 2 HALVES OF THE COUTS instead of 4 rows
+// -- a 2 x 32 tile, twice the workgroups, half the serial MFMA chain per wave.  One 128 x 128 image is 128 tiles of 4 x 32:
+// 512 waves on the chip's 1024 SIMDs, each running ONE chain of 6400 fp32 MFMAs (171 us at 2.4 GHz); split, it is 1024 waves
+// of 3200.  Every output is still the same fma chain over k in the same order (a wave owns whole cout tiles), so results are
+// bit-identical to the unsplit kernel; the chained 1x1 needs all 128 intermediate channels of a pixel row, which now sit in
+// two waves: they meet through LDS (free after the last stage) in the accumulator layout, which IS the B operand layout.
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
 __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid) {
+  static_assert(!CSPLIT || (PSEG == 1 && NW == 4 && COUT % 64 == 0 && !GATE), "the cout-split form is a small-grid plain / chained conv");
   constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
-  constexpr int TW = 32, TH = NW * PSEG;
+  constexpr int TW = 32, TH = (CSPLIT ? NW / 2 : NW) * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
   constexpr int CK = ConvCfg<KS, CIN>::CK;
   constexpr int NCHUNK = CIN / CK;
   constexpr int XS = CK * XR * XQ;    // floats per input tile
   constexpr int WS = CK * KS * COUT;  // floats per weight stage
-  constexpr int CT = COUT / 32;
+  constexpr int CTALL = COUT / 32, CT = CSPLIT ? CTALL / 2 : CTALL;   // cout tiles of the conv / of one wave
   constexpr int NST = NCHUNK * KS;
   constexpr int W4 = WS / 4;            // float4 per weight stage
   constexpr int WE = (W4 + NT - 1) / NT;  // float4 per thread per stage
@@ -132,6 +139,8 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   const int wave = tid >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
+  const int wrow = CSPLIT ? (wave & 1) : wave;          // this wave's pixel-row segment inside the tile
+  const int cbase = CSPLIT ? (wave >> 1) * CT : 0;      // ... and its first cout tile
 
   CODON_TSTAMP(p.dbg, 0)
   const int tx = bid % p.tiles_x;
@@ -289,8 +298,8 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
     // alone, hipcc pairs them into ds_read2_b32 (8-bit offsets) and pays a v_add_u32 re-base per pair -- VALU ops
     // that cost matrix-pipe time, where the extra LDS instructions are free.
     typedef const volatile __attribute__((address_space(3))) float* lds_cvp;
-    const lds_cvp xb = (lds_cvp)(xs0 + (chunk & 1) * XSP + (half * XR + wave * PSEG + dy) * XQ + l31);
-    const lds_cvp wb = (lds_cvp)(ws0 + (s & 1) * WSP + half * (KS * COUT) + l31);
+    const lds_cvp xb = (lds_cvp)(xs0 + (chunk & 1) * XSP + (half * XR + wrow * PSEG + dy) * XQ + l31);
+    const lds_cvp wb = (lds_cvp)(ws0 + (s & 1) * WSP + half * (KS * COUT) + l31 + cbase * 32);
     // operand fetch for group g = (dx, cp) is issued one group ahead of its MFMAs (two register sets)
     constexpr int NG = KS * (CK / 2);
     float a[2][CT], bv[2][PSEG];
@@ -332,7 +341,7 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   unsigned vo[PSEG];
 #pragma unroll
   for (int i = 0; i < PSEG; ++i) {
-    const int gy = ty0 + wave * PSEG + i;
+    const int gy = ty0 + wrow * PSEG + i;
     vo[i] = (gx < W && gy < H) ? (unsigned)(4 * half) * HW4 + 4u * (unsigned)(gy * W + gx) : BUF_OOB;
   }
   const bool relu = p.flags & CODON_CONV_RELU;
@@ -358,12 +367,56 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
       const float* const ybase = p.y + (long)b * p.y_img + p.y_base;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        const __amdgpu_buffer_rsrc_t yr_ = planes(ybase, t * 32, 32);
+        const __amdgpu_buffer_rsrc_t yr_ = planes(ybase, (cbase + t) * 32, 32);
 #pragma unroll
         for (int i = 0; i < PSEG; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) buf_st(acc[i][t][r], yr_, vo[i], inplane(r));
       }
+    }
+    if constexpr (CSPLIT) {
+      // the row's 128 intermediate channels: this wave's two tiles and its partner's two, through LDS as [tile][r][lane]
+      // (the staging buffers are free: every wave is past the last stage's barrier)
+      static_assert(2 * CTALL * 16 * 64 <= 2 * XSP + 2 * WSP, "the exchange fits the stage buffers");
+      float* const xc = lds + wrow * (CTALL * 16 * 64);
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[((cbase + t) * 16 + r) * 64 + lane] = acc[0][t][r];
+      __syncthreads();
+      const int t2 = wave >> 1;                            // this wave's tile of the 64 output channels
+      const __amdgpu_buffer_rsrc_t w2r_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, BUF_FLAGS);
+      const unsigned w2o_ = (unsigned)lane * 64u;
+      f32x16 d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < CTALL; ++t) {                    // k in the order of the unsplit kernel: tiles 0..3, registers 0..15
+        float4 a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(w2r_, w2o_, (unsigned)((t2 * CTALL + t) * 4096 + q * 16), 0);
+          a4[q] = *reinterpret_cast<const float4*>(&v_);
+        }
+        const float* a = reinterpret_cast<const float*>(a4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], xc[(t * 16 + r) * 64 + lane], d, 0, 0, 0);
+      }
+      const float* const y2b_ = p.y2 + (long)b * p.y2_img + p.y2_base;
+      const __amdgpu_buffer_rsrc_t y2r_ = planes(y2b_, t2 * 32, 32), rr_ = planes(rbase, t2 * 32, 32);
+      if (p.res) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = buf_ld(rr_, vo[0], inplane(r));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf_st(d[r] + rv[r], y2r_, vo[0], inplane(r));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf_st(d[r], y2r_, vo[0], inplane(r));
+      }
+      CODON_TSTAMP(p.dbg, 4)
+      return;
     }
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, BUF_FLAGS);
     const float* const y2base = p.y2 + (long)b * p.y2_img + p.y2_base;
@@ -421,7 +474,7 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
     constexpr bool MS = decltype(ms_c)::value;      // MASK_SUM: the mask applies to conv + previous value
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-      const __amdgpu_buffer_rsrc_t yrsrc = planes(ybase, t * 32, 32), rrsrc = planes(rbase, t * 32, 32);
+      const __amdgpu_buffer_rsrc_t yrsrc = planes(ybase, (cbase + t) * 32, 32), rrsrc = planes(rbase, (cbase + t) * 32, 32);
 #pragma unroll
       for (int i = 0; i < PSEG; ++i) {
         float rv[16], av[16];
@@ -472,9 +525,9 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   CODON_TSTAMP(p.dbg, 4)
 }
 
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvParams p) {
-  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW>(p, xcd_remap(blockIdx.x, (unsigned)p.nblk));
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>(p, xcd_remap(blockIdx.x, (unsigned)p.nblk));
 }
 
 // Two convs of one shape and kernel variant as ONE grid of 2 * nblk workgroups (codon_conv_pair_begin / _end): the depth and
@@ -533,6 +586,7 @@ int pack_chain1x1_f32(const float* w, float* out, hipStream_t stream) {
 // tiles instead (PSEG = 1: twice the workgroups, half the MFMAs each).  Per-pixel arithmetic and its order are the
 // same, so results stay bit-identical to the large-grid kernels (batch-independence tests compare the two).
 constexpr long SMALL_GRID = 384;
+constexpr long CSPLIT_MAX_BLOCKS = 192;     // 4 x 32 tiles: up to here a lone launch leaves a quarter of the SIMDs without a wave
 static bool small_grid(const codon_conv_desc* d) {
   return (long)((d->width + 31) / 32) * ((d->height + 7) / 8) * d->batch < SMALL_GRID;
 }
@@ -605,10 +659,10 @@ static int launch_or_hold_f32(const ConvParams& p, bool small, hipStream_t strea
   return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, false>(&p, stream);
 }
 
-template <int KS, int CIN, int COUT, int PSEG>
+template <int KS, int CIN, int COUT, int PSEG, bool CSPLIT = false>
 static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* w, float* y,
                          const float* res, hipStream_t stream) {
-  constexpr int TH = 4 * PSEG;
+  constexpr int TH = (CSPLIT ? 2 : 4) * PSEG;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res;
   p.H = d->height; p.W = d->width;
@@ -629,13 +683,25 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.gout = nullptr; p.go_img = p.go_base = 0;
+  if constexpr (CSPLIT) {          // a lone small launch (see conv_chain1x1_fwd_f32): 2 x 32 tiles, couts split over the waves
+    constexpr auto kern = conv_mfma_f32_kernel<KS, CIN, COUT, 1, false, false, 4, true>;
+    const unsigned dyn = solo_lds_pad<kern>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), dyn, stream, p);
+    return check_launch("conv_mfma_f32_kernel<cout split>");
+  }
   return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && small_grid(d), stream);
 }
 
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_conv(const codon_conv_desc* d, const float* x, const float* w, float* y,
                        const float* res, hipStream_t stream) {
-  if (small_grid(d)) return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, stream);
+  if (small_grid(d)) {
+    if constexpr (COUT % 64 == 0 && KS != 1) {
+      const long nblk4 = (long)((d->width + 31) / 32) * ((d->height + 3) / 4) * d->batch;
+      if (!pair_recorder() && nblk4 <= CSPLIT_MAX_BLOCKS) return launch_conv_p<KS, CIN, COUT, 1, true>(d, x, w, y, res, stream);
+    }
+    return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, stream);
+  }
   return launch_conv_p<KS, CIN, COUT, PSEG>(d, x, w, y, res, stream);
 }
 
@@ -718,6 +784,16 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
+  if (small && !pair_recorder() && nblk <= CSPLIT_MAX_BLOCKS) {
+    // alone on the chip with at most 192 tiles of 4 x 32 (the trunk's conv10 + confuse_fuse at one image per call: the two
+    // streams of a block leave as a pair and fill the chip by themselves): 2 x 32 tiles, couts split over the waves
+    p.tiles_y = (d->height + 1) / 2;
+    p.nblk = (int)((long)p.tiles_x * p.tiles_y * d->batch);
+    constexpr auto kern = conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC, true>;
+    const unsigned dyn = solo_lds_pad<kern>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(NWC * 64), dyn, stream, p);
+    return check_launch("conv_mfma_f32_kernel<fused 1x1, cout split>");
+  }
   if (small) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, true, stream);
   return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC>(p, false, stream);
 }

@@ -956,3 +956,55 @@ def test_conv_pair_fp32_small_grid():
         ops.conv2d(Slice(big_x, 0, 64), w5a, Slice(yb, 0, 64), 5)
         ops.conv2d(Slice(big_x, 64, 64), w5b, Slice(yb, 64, 64), 5)
     assert pr.launches == 0                # both launched at once, nothing was held
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 96), (1, 37, 70), (2, 33, 40), (1, 1, 1), (1, 128, 128)])
+def test_fp32_cout_split_chained_conv_is_bit_identical(shape):
+    """conv_mfma_f32 CSPLIT (round 5): a lone small-grid conv5x5 128->128 + chained 1x1 runs as 2 x 32 tiles whose four waves are
+    2 rows x 2 cout halves (half the serial MFMA chain per wave; the 1x1's operands meet through LDS).  Every output is the same
+    fma chain in the same order: bit-identical to the unsplit small-grid kernel -- which a one-call pair bracket selects --
+    with and without the residual and the materialised intermediate."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    x = _rand((B, 128, H, W), 1).to(dev)
+    res = _rand((B, 64, H, W), 2).to(dev)
+    w5 = ops.packed_weight(_rand((128, 128, 5, 5), 3, (2.0 / (25 * 128)) ** 0.5).to(dev), L.PACK_FWD, torch.float32)
+    w1 = ops.packed_weight(_rand((64, 128, 1, 1), 4, 0.1).to(dev), L.PACK_CHAIN1X1, torch.float32)
+    for use_res, use_mid in ((False, False), (True, False), (True, True)):
+        outs = []
+        for bracket in (False, True):
+            o = torch.full((B, 128, H, W), float("nan"), device=dev)
+            mid = torch.full((B, 128, H, W), float("nan"), device=dev)
+            with ops.conv_pair(dev, bracket) as pr:
+                ops.conv_chain1x1(Slice(x), w5, w1, Slice(o, 64, 64), mid=Slice(mid) if use_mid else None,
+                                  residual=Slice(res) if use_res else None)
+            assert not bracket or pr.launches == 1
+            outs.append((o, mid))
+        assert torch.equal(outs[0][0][:, 64:], outs[1][0][:, 64:]) and torch.isnan(outs[0][0][:, :64]).all()
+        if use_mid:
+            assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("k,cin,cout", [(5, 64, 64), (3, 64, 64), (3, 128, 64), (3, 64, 128), (5, 128, 128)])
+def test_fp32_cout_split_plain_conv_is_bit_identical(k, cin, cout):
+    """The same split for a lone small-grid plain conv (the trunk's conv8 / conv9 / conv11 at one image per call), every
+    epilogue variant: ReLU, residual, ReLU mask, accumulate, mask of the sum."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    for (B, H, W) in ((1, 64, 96), (1, 37, 70), (1, 2, 3)):
+        x = _rand((B, cin, H, W), 1).to(dev)
+        r = _rand((B, cout, H, W), 2).to(dev)
+        prev = _rand((B, cout, H, W), 3).to(dev)
+        wp = ops.packed_weight(_rand((cout, cin, k, k), 4, (2.0 / (k * k * cout)) ** 0.5).to(dev), L.PACK_FWD, torch.float32)
+        for kw in (dict(relu=True), dict(residual=Slice(r)), dict(relu_mask=Slice(r)), dict(accumulate=True),
+                   dict(relu_mask=Slice(r), accumulate=True, mask_sum=True)):
+            ys = []
+            for bracket in (False, True):
+                y = prev.clone()
+                with ops.conv_pair(dev, bracket):
+                    ops.conv2d(Slice(x), wp, Slice(y), k, **kw)
+                ys.append(y)
+            assert torch.equal(ys[0], ys[1]), (k, cin, cout, H, W, list(kw))
