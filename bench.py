@@ -229,6 +229,18 @@ def cpu_baseline(H, W):
             "config0_1x128x128": {"min_s": c1[0], "median_s": c1[2], "runs": 5}}
 
 
+def _latency_ms(fn, dev, warm=20, n=50):
+    """Steady-state milliseconds per call: `n` calls after `warm` warm-up calls, device synchronised on both sides."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 def config0_gpu_latency(dev):
     """BASELINE.json configs[0] (1 x 128 x 128 pair, fp32) on the GPU, beside the CPU number for the same case: the
     reference script's own use (one image per call, test.py:125).  ~95 kernel launches per forward: eager is
@@ -242,22 +254,16 @@ def config0_gpu_latency(dev):
     with torch.no_grad():
         gm = GraphedCODON(m, x, y)
         for name, fn in (("eager_ms", lambda: m(x, y)), ("hipgraph_replay_ms", lambda: gm(x, y))):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(20):
-                fn()
-            torch.cuda.synchronize(dev)
-            out[name] = (time.perf_counter() - t0) / 20 * 1e3
+            out[name] = _latency_ms(fn, dev)
     out["workload"] = "CODON x4 forward, 1 x 128 x 128 pair, fp32 exact (BASELINE.json configs[0]) on 1 MI355X"
+    out["protocol"] = "steady state: mean of 50 calls after 20 warm-up calls (the first ~20 calls after an idle gap run 3 % slower: clock ramp, tools/probes/b1_warm.py)"
     return out
 
 
 def script_pattern_latency(dev):
     """The reference script's real use (CODON_X4/test.py:52,116-125): ONE image per call, model.cuda().half(), at the
     sizes of the shipped Middlebury samples (370x463, 375x450, 247x343) -- eager and as a hipGraph replay, in fp16 and
-    in fp32.  Milliseconds per forward (mean of 20 after 3 warm-ups)."""
+    in fp32.  Milliseconds per forward, steady state (mean of 50 after 20 warm-up calls)."""
     from codon_amd import CODONNet
     from codon_amd.graph import GraphedCODON
     torch.manual_seed(0)
@@ -271,14 +277,7 @@ def script_pattern_latency(dev):
             with torch.no_grad():
                 gm = GraphedCODON(m, x, y)
                 for name, fn in (("eager", lambda: m(x, y)), ("hipgraph", lambda: gm(x, y))):
-                    for _ in range(3):
-                        fn()
-                    torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    for _ in range(20):
-                        fn()
-                    torch.cuda.synchronize(dev)
-                    res[f"{dt_name}_{H}x{W}_{name}_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+                    res[f"{dt_name}_{H}x{W}_{name}_ms"] = _latency_ms(fn, dev)
             del gm
         del m
     return res

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Run ON THE GPU BOX (gpurun -- bash tools/profile_round.sh r04): bench records + rocprofv3 summaries of one round.
+# Run ON THE GPU BOX (gpurun -- bash tools/profile_round.sh r05): bench records + rocprofv3 summaries of one round.
 # Everything lands under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 # Every rocprofv3 command puts the program itself (python3 bench.py ...) directly after "--"; counters are collected in
 # their own runs (no trace domains besides --kernel-trace), FETCH_SIZE / WRITE_SIZE / clock+busy in separate passes.
 # One stderr file per command (round 3 wrote five runs into one .err: only the last survived).
 set -e -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 # (the box is fresh on every gpurun call; LOCALLY gpurun_out/ accumulates: regenerate tables only from the newest counter CSV per directory)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
@@ -47,4 +47,8 @@ run train_bf16 --mode train --dtype bf16 --steps 10 --warmup 2
 run bench_x8_f32 --scale 8 --batch 16 --height 960 --width 1280 --steps 3 --warmup 1 --no-cpu-baseline --no-fwd-bwd
 run bench_x16_bf16 --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 --steps 5 --warmup 2 --no-cpu-baseline
 run bench_rmcr_f32 --model rmcr --steps 3 --warmup 1 --no-cpu-baseline
+# one image per call (the reference script's own pattern): kernel statistics + one forward's timeline
+cd $ROOT
+bash tools/probes/trace_b1.sh ${tag}_b1_fp16_370x463 fp16 370 463 > $OUT/${tag}_b1_fp16.log 2>&1
+bash tools/probes/trace_b1.sh ${tag}_b1_fp32_128x128 fp32 128 128 > $OUT/${tag}_b1_fp32.log 2>&1
 echo done
