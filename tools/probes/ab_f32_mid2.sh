@@ -1,0 +1,12 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/f32mid; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for t in "$@"; do
+  TB=$ROOT/ab/$t/trace_b1.py
+  rm -rf $OUT/$t
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$t -- python3 $TB fp32 370 463 20 > $OUT/$t.log 2>&1
+  f=$(find $OUT/$t -name "*kernel_stats.csv" | head -1); cp $f $OUT/${t}_stats.csv
+  find $OUT/$t -name "*kernel_trace.csv" -delete
+  echo "== $t"; head -8 $OUT/${t}_stats.csv | cut -c1-150
+done
