@@ -591,6 +591,30 @@ static bool small_grid(const codon_conv_desc* d) {
   return (long)((d->width + 31) / 32) * ((d->height + 7) / 8) * d->batch < SMALL_GRID;
 }
 
+// GRIDS OF A FEW ROUNDS (one image of a few hundred rows).  Two 4-wave workgroups share a CU, and a CU gives a lone workgroup
+// almost the throughput it gives two: 8 x 32 tiles of the chained conv take 0.72 ms as a pair and 0.36 ms alone.  So a launch
+// runs in rounds of 512 workgroups, and its last round costs a full pair time wherever the dispatcher happens to put two
+// of the leftover workgroups on one CU: 705 tiles (1 x 370 x 463) ran in 1.10 ms or in 1.43 ms depending on nothing the
+// host controls (profiles/r05_grid_rounds.txt: same kernel, same operands, two builds).  Priced that way -- the last round
+// at its full price -- the three ways to tile a launch are
+//   8 x 32 tiles, two per CU:   ceil(n8 / 512) rounds of 3.945   (units: half a 4 x 32 pair round, 0.1835 ms on the chain)
+//   4 x 32 tiles, two per CU:   ceil(n4 / 512) rounds of 2
+//   4 x 32 tiles, one per CU:   ceil(n4 / 256) rounds of SOLO    (the LDS padding of solo_lds_pad; no pairing to be lucky with)
+// and the cheapest is taken.  8 x 32 wins by 1.4 % once the rounds are many (the headline batch: 75 rounds); the ratios
+// were measured on 15 image heights between 200 and 820 rows (tools/probes/grid_mode_sweep.sh).  Per-pixel arithmetic and
+// its order do not depend on the tiling: same bits.  3 x 3 and 1 x 1 convs (memory-bound, no such step pattern) keep 8 x 32.
+enum GridMode { GRID_8X32, GRID_4X32, GRID_4X32_SOLO };
+constexpr float GRID_SOLO_CHAIN = 1.093f, GRID_SOLO_CONV64 = 1.184f;
+static GridMode grid_mode(const codon_conv_desc* d, float solo) {
+  if (small_grid(d)) return GRID_4X32_SOLO;
+  const long tx = (d->width + 31) / 32;
+  const long n8 = tx * ((d->height + 7) / 8) * d->batch, n4 = tx * ((d->height + 3) / 4) * d->batch;
+  const float c8 = 3.945f * (float)((n8 + 511) / 512), c4 = 2.f * (float)((n4 + 511) / 512);
+  const float cs = solo * (float)((n4 + 255) / 256);
+  if (c8 <= c4 && c8 <= cs) return GRID_8X32;
+  return c4 <= cs ? GRID_4X32 : GRID_4X32_SOLO;
+}
+
 // Small grids leave CUs empty, and the host runs the two streams of a block on two HIP streams (model.py) -- but the
 // dispatcher puts the workgroups of two concurrent 128-workgroup launches on the SAME CUs (rocprofv3 trace: both overlap in
 // time and each takes 345 us instead of 202).  A dynamic-LDS request that brings a workgroup above half of the CU's 160 KB
@@ -661,7 +685,7 @@ static int launch_or_hold_f32(const ConvParams& p, bool small, hipStream_t strea
 
 template <int KS, int CIN, int COUT, int PSEG, bool CSPLIT = false>
 static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* w, float* y,
-                         const float* res, hipStream_t stream) {
+                         const float* res, bool solo, hipStream_t stream) {
   constexpr int TH = (CSPLIT ? 2 : 4) * PSEG;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res;
@@ -689,27 +713,30 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), dyn, stream, p);
     return check_launch("conv_mfma_f32_kernel<cout split>");
   }
-  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && small_grid(d), stream);
+  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && solo, stream);
 }
 
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_conv(const codon_conv_desc* d, const float* x, const float* w, float* y,
                        const float* res, hipStream_t stream) {
-  if (small_grid(d)) {
+  const GridMode mode = KS == 5 ? grid_mode(d, GRID_SOLO_CONV64) : small_grid(d) ? GRID_4X32_SOLO : GRID_8X32;
+  if (mode == GRID_4X32_SOLO) {
     if constexpr (COUT % 64 == 0 && KS != 1) {
       const long nblk4 = (long)((d->width + 31) / 32) * ((d->height + 3) / 4) * d->batch;
-      if (!pair_recorder() && nblk4 <= CSPLIT_MAX_BLOCKS) return launch_conv_p<KS, CIN, COUT, 1, true>(d, x, w, y, res, stream);
+      if (!pair_recorder() && nblk4 <= CSPLIT_MAX_BLOCKS) return launch_conv_p<KS, CIN, COUT, 1, true>(d, x, w, y, res, true, stream);
     }
-    return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, stream);
+    return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, true, stream);
   }
-  return launch_conv_p<KS, CIN, COUT, PSEG>(d, x, w, y, res, stream);
+  if (mode == GRID_4X32) return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, false, stream);
+  return launch_conv_p<KS, CIN, COUT, PSEG>(d, x, w, y, res, false, stream);
 }
 
 int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
 
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
-                          const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
+                          const float* sp, const float* w, float* y, const codon_tensor* gated_out, bool solo,
+                          hipStream_t stream) {
   constexpr int TH = 4 * PSEG;
   ConvParams p;
   p.x = pre; p.w = w; p.y = y; p.res = nullptr;
@@ -733,14 +760,15 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, true, 4>(p, PSEG == 1 && small_grid(d), stream);
+  return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, true, 4>(p, PSEG == 1 && solo, stream);
 }
 
 template <int KS, int CIN, int COUT>
 static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
                         const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
-  if (small_grid(d)) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, gated_out, stream);
-  return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, gated_out, stream);
+  const GridMode mode = KS == 5 ? grid_mode(d, GRID_SOLO_CONV64) : small_grid(d) ? GRID_4X32_SOLO : GRID_8X32;
+  if (mode != GRID_8X32) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, gated_out, mode == GRID_4X32_SOLO, stream);
+  return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, gated_out, false, stream);
 }
 
 int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
@@ -762,8 +790,9 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
   constexpr int NWC = 4;     // waves per workgroup (one 8-wave workgroup per CU on a 16x32 tile measured slower: DESIGN.md 3.1)
-  const bool small = small_grid(d);
-  const int TH = (small ? 1 : 2) * NWC;
+  const GridMode mode = grid_mode(d, GRID_SOLO_CHAIN);
+  const bool small = mode == GRID_4X32_SOLO;
+  const int TH = (mode == GRID_8X32 ? 2 : 1) * NWC;
   ConvParams p;
   p.x = x; p.w = w; p.y = y; p.res = res ? (const float*)res->data : nullptr;
   p.H = d->height; p.W = d->width;
@@ -794,7 +823,7 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
     hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(NWC * 64), dyn, stream, p);
     return check_launch("conv_mfma_f32_kernel<fused 1x1, cout split>");
   }
-  if (small) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, true, stream);
+  if (mode != GRID_8X32) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, small, stream);
   return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC>(p, false, stream);
 }
 

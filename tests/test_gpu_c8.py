@@ -949,9 +949,8 @@ def test_conv_pair_fp32_small_grid():
     o1, ns = run(True)
     assert ns == [1, 1, 1, 1], ns
     assert all(torch.equal(a, b) for a, b in zip(o0, o1))
-    big_x = _rand((4, 128, 96, 128), 9).to(dev)           # 4 x 12 x 4 = 192... x 2 rows: a LARGE grid (>= 384 tiles of 8 x 32)
-    big_x = _rand((8, 128, 96, 128), 9).to(dev)
-    yb = torch.zeros((8, 128, 96, 128), device=dev)
+    big_x = _rand((16, 128, 96, 128), 9).to(dev)          # 16 x 12 x 4 = 768 tiles of 8 x 32: priced onto 4 x 32 tiles two per CU
+    yb = torch.zeros((16, 128, 96, 128), device=dev)       # (grid_mode), which is not a pair form
     with ops.conv_pair(dev) as pr:
         ops.conv2d(Slice(big_x, 0, 64), w5a, Slice(yb, 0, 64), 5)
         ops.conv2d(Slice(big_x, 64, 64), w5b, Slice(yb, 64, 64), 5)
@@ -1008,3 +1007,39 @@ def test_fp32_cout_split_plain_conv_is_bit_identical(k, cin, cout):
                     ops.conv2d(Slice(x), wp, Slice(y), k, **kw)
                 ys.append(y)
             assert torch.equal(ys[0], ys[1]), (k, cin, cout, H, W, list(kw))
+
+
+def test_fp32_grid_modes_are_bit_identical():
+    """conv_mfma_f32 grid_mode (round 5): a launch of a few rounds of workgroups picks 8 x 32 tiles, 4 x 32 tiles two per CU or
+    4 x 32 tiles one per CU by a cost model of its rounds.  At 300 x 463 one image is priced onto 4 x 32 one-per-CU for the
+    chained conv, at 370 x 463 onto 4 x 32 two-per-CU, and five such images onto 8 x 32: every image of the batch must come
+    out with the bits it gets on its own -- plain 5x5 (all epilogues that the one-image forward and backward use), gated +
+    emitting, and chained 1x1 with and without residual."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    W = 463
+    wt = lambda co, ci, k, seed, mode=L.PACK_FWD: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), mode, torch.float32)
+    w5, w1, w564 = wt(128, 128, 5, 1), wt(64, 128, 1, 2, L.PACK_CHAIN1X1), wt(64, 64, 5, 3)
+    for H in (300, 370):
+        B = 5
+        x = _rand((B, 128, H, W), 4).to(dev)
+        r = _rand((B, 64, H, W), 5).to(dev)
+        ch, sp = torch.rand((B, 64), device=dev), torch.rand((B, 1, H, W), device=dev)
+
+        def run(xs, rs, chs, sps):
+            b = xs.shape[0]
+            o = [torch.zeros((b, 128, H, W), device=dev) for _ in range(4)]
+            ops.conv_chain1x1(Slice(xs), w5, w1, Slice(o[0], 64, 64))
+            ops.conv_chain1x1(Slice(xs), w5, w1, Slice(o[0], 0, 64), residual=Slice(rs))
+            ops.conv2d(Slice(xs, 0, 64), w564, Slice(o[1], 0, 64), 5, relu=True)
+            ops.conv2d(Slice(xs, 64, 64), w564, Slice(o[1], 64, 64), 5, residual=Slice(rs))
+            ops.conv2d(Slice(xs, 64, 64), w564, Slice(o[1], 64, 64), 5, relu_mask=Slice(rs), accumulate=True, mask_sum=True)
+            ops.conv2d_gated(Slice(xs, 0, 64), Slice(xs, 64, 64), chs, sps, w564, Slice(o[2], 0, 64), 5, relu=True, emit=Slice(o[3], 64, 64))
+            return o
+
+        full = run(x, r, ch, sp)
+        for i in (0, B - 1):
+            one = run(x[i:i + 1].contiguous(), r[i:i + 1].contiguous(), ch[i:i + 1].contiguous(), sp[i:i + 1].contiguous())
+            for a, b_ in zip(full, one):
+                assert torch.equal(a[i:i + 1], b_), (H, i)
