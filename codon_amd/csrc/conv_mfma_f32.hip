@@ -537,12 +537,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
 struct ConvPair {
   ConvParams a, b;
 };
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_pair_kernel(const ConvPair pp) {
   const unsigned nblk = (unsigned)pp.a.nblk;                       // == pp.b.nblk (checked on the host)
   const unsigned v = xcd_remap(blockIdx.x, 2u * nblk);
   const bool second = v >= nblk;                                   // workgroup-uniform
-  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW>(second ? pp.b : pp.a, second ? v - nblk : v);
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>(second ? pp.b : pp.a, second ? v - nblk : v);
 }
 
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
@@ -587,6 +587,7 @@ int pack_chain1x1_f32(const float* w, float* out, hipStream_t stream) {
 // same, so results stay bit-identical to the large-grid kernels (batch-independence tests compare the two).
 constexpr long SMALL_GRID = 384;
 constexpr long CSPLIT_MAX_BLOCKS = 192;     // 4 x 32 tiles: up to here a lone launch leaves a quarter of the SIMDs without a wave
+constexpr long CSPLIT_PAIR_MAX_BLOCKS = 128;   // ... and a PAIR of launches split this way is at most 512 workgroups: one round
 static bool small_grid(const codon_conv_desc* d) {
   return (long)((d->width + 31) / 32) * ((d->height + 7) / 8) * d->batch < SMALL_GRID;
 }
@@ -652,22 +653,35 @@ static unsigned solo_lds_pad() {  // kernels of the same signature, i.e. give ev
 
 // one launch of a filled parameter block / two blocks of the same variant as one grid (pair.h).  `small` launches ask for the
 // solo-LDS padding so that every workgroup has a CU to itself.
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false>
 static int launch_single_f32(const void* pv, hipStream_t stream) {
   const ConvParams& p = *static_cast<const ConvParams*>(pv);
-  const unsigned dyn = SOLO ? solo_lds_pad<conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>>() : 0u;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>), dim3((unsigned)p.nblk), dim3(NW * 64), dyn, stream, p);
-  return check_launch("conv_mfma_f32_kernel");
+  constexpr auto kern = conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>;
+  const unsigned dyn = SOLO ? solo_lds_pad<kern>() : 0u;
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(NW * 64), dyn, stream, p);
+  return check_launch(CSPLIT ? "conv_mfma_f32_kernel<cout split>" : "conv_mfma_f32_kernel");
 }
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO>
+// CSPLIT pairs (2 x 32 tiles, couts split over the waves): up to 256 workgroups in all take a CU each; 257 .. 512 run two to
+// a CU with no padding -- each SIMD then holds two waves of half the serial MFMA chain, which hide each other's stage waits
+// (BASELINE configs[0]: the pair of chained convs 225 -> 218 us, of 5x5 64->64 convs 62 -> 57, of 3x3 26 -> 24).
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false>
 static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
   ConvPair pp;
   pp.a = *static_cast<const ConvParams*>(av);
   pp.b = *static_cast<const ConvParams*>(bv);
-  const unsigned dyn = SOLO ? solo_lds_pad<conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>>() : 0u;
-  hipLaunchKernelGGL((conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW>), dim3(2u * (unsigned)pp.a.nblk),
-                     dim3(NW * 64), dyn, stream, pp);
+  constexpr auto kern = conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>;
+  const bool solo = SOLO && (!CSPLIT || 2 * pp.a.nblk <= 256);
+  const unsigned dyn = solo ? solo_lds_pad<kern>() : 0u;
+  hipLaunchKernelGGL(kern, dim3(2u * (unsigned)pp.a.nblk), dim3(NW * 64), dyn, stream, pp);
   return check_launch("conv_mfma_f32_pair_kernel");
+}
+// a cout-split launch: held back by an open pair bracket, else alone with a CU per workgroup
+template <int KS, int CIN, int COUT, bool FUSE, int NW>
+static int launch_or_hold_csplit_f32(const ConvParams& p, hipStream_t stream) {
+  if (pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>,
+                &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>))
+    return CODON_OK;
+  return launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>(&p, stream);
 }
 // small-grid launches (PSEG = 1) can be held back by an open pair bracket; everything else launches at once
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW>
@@ -707,12 +721,8 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.gout = nullptr; p.go_img = p.go_base = 0;
-  if constexpr (CSPLIT) {          // a lone small launch (see conv_chain1x1_fwd_f32): 2 x 32 tiles, couts split over the waves
-    constexpr auto kern = conv_mfma_f32_kernel<KS, CIN, COUT, 1, false, false, 4, true>;
-    const unsigned dyn = solo_lds_pad<kern>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), dyn, stream, p);
-    return check_launch("conv_mfma_f32_kernel<cout split>");
-  }
+  if constexpr (CSPLIT)            // a small launch (see conv_chain1x1_fwd_f32): 2 x 32 tiles, couts split over the waves
+    return launch_or_hold_csplit_f32<KS, CIN, COUT, false, 4>(p, stream);
   return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && solo, stream);
 }
 
@@ -723,7 +733,8 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
   if (mode == GRID_4X32_SOLO) {
     if constexpr (COUT % 64 == 0 && KS != 1) {
       const long nblk4 = (long)((d->width + 31) / 32) * ((d->height + 3) / 4) * d->batch;
-      if (!pair_recorder() && nblk4 <= CSPLIT_MAX_BLOCKS) return launch_conv_p<KS, CIN, COUT, 1, true>(d, x, w, y, res, true, stream);
+      if (nblk4 <= (pair_recorder() ? CSPLIT_PAIR_MAX_BLOCKS : CSPLIT_MAX_BLOCKS))
+        return launch_conv_p<KS, CIN, COUT, 1, true>(d, x, w, y, res, true, stream);
     }
     return launch_conv_p<KS, CIN, COUT, 1>(d, x, w, y, res, true, stream);
   }
@@ -813,15 +824,12 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
-  if (small && !pair_recorder() && nblk <= CSPLIT_MAX_BLOCKS) {
-    // alone on the chip with at most 192 tiles of 4 x 32 (the trunk's conv10 + confuse_fuse at one image per call: the two
-    // streams of a block leave as a pair and fill the chip by themselves): 2 x 32 tiles, couts split over the waves
+  if (small && nblk <= (pair_recorder() ? CSPLIT_PAIR_MAX_BLOCKS : CSPLIT_MAX_BLOCKS)) {
+    // at most 192 tiles of 4 x 32 alone on the chip (the trunk's conv10 + confuse_fuse at one image per call), or at most
+    // 128 in each launch of a pair (the two streams of a block): 2 x 32 tiles, couts split over the waves
     p.tiles_y = (d->height + 1) / 2;
     p.nblk = (int)((long)p.tiles_x * p.tiles_y * d->batch);
-    constexpr auto kern = conv_mfma_f32_kernel<5, 128, 128, 1, true, false, NWC, true>;
-    const unsigned dyn = solo_lds_pad<kern>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(NWC * 64), dyn, stream, p);
-    return check_launch("conv_mfma_f32_kernel<fused 1x1, cout split>");
+    return launch_or_hold_csplit_f32<5, 128, 128, true, NWC>(p, stream);
   }
   if (mode != GRID_8X32) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, small, stream);
   return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC>(p, false, stream);

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 // fetched (R + 2) / R times instead of 3 (round 1: one row per thread, 6.08 GB moved for 2.60 GB algorithmic -- the
 // vertically adjacent rows sat in other workgroups on other XCDs, whose L2s each fetched them again).
 // VEC = 4 (16-byte accesses); VEC = 1 for widths that are not a multiple.  16-bit activations: head_c8_kernel (ew_c8.hip).
-template <int VEC, int R, typename T>
+// DEPTH channels are fetched before the first of them is used: one 128 x 128 image is 32 waves, and a wave that waits for
+// every channel's rows before it asks for the next one's is 64 memory round trips long (57 us; 4 in flight: 37 us).  The
+// channels are still accumulated one after the other in the same order: same bits.
+template <int VEC, int R, typename T, int DEPTH = 1>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ res, float* __restrict__ y, int H,
                                                    int W, long x_img, long x_base, int nband, int nseg, int nwave,
@@ -212,11 +215,14 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, cons
         o[r][i] = a;
       }
   };
+  static_assert(64 % DEPTH == 0, "whole groups of channels");
 #pragma unroll 1
-  for (int c = 0; c < 64; ++c) {
-    float ra[R + 2][VEC + 2];
-    load_rows(c, ra);
-    accumulate(c, ra);
+  for (int c = 0; c < 64; c += DEPTH) {
+    float ra[DEPTH][R + 2][VEC + 2];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_rows(c + d, ra[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) accumulate(c + d, ra[d]);
   }
   if (!act) return;
 #pragma unroll
@@ -272,7 +278,7 @@ int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y
                             stream);
 }
 
-template <int VEC, int R, typename T>
+template <int VEC, int R, typename T, int DEPTH = 1>
 static int head_launch_v(int B, int H, int W, const T* x, int x_ctotal, int x_coff, const float* w, const float* res,
                          float* y, hipStream_t stream) {
   const long HW = (long)H * W;
@@ -281,7 +287,7 @@ static int head_launch_v(int B, int H, int W, const T* x, int x_ctotal, int x_co
   const long nwave = (long)B * nband * nseg;
   const long blocks = (nwave + 3) / 4;
   CODON_REQUIRE(nwave < (1L << 31), CODON_ERR_UNSUPPORTED, "head_fwd: grid too large");
-  hipLaunchKernelGGL((head_kernel<VEC, R, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
+  hipLaunchKernelGGL((head_kernel<VEC, R, T, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W,
                      x_ctotal * HW, x_coff * HW, nband, nseg, (int)nwave, (int)blocks);
   return check_launch("head_kernel");
 }
@@ -312,8 +318,9 @@ static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff
   const bool big = (long)B * H * W >= (1L << 22);
   if (v4)
     return big ? head_launch_v<4, 16, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream)
-               : head_launch_v<4, 4, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
-  return head_launch_v<1, 4, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
+               : head_launch_v<4, 4, T, 4>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
+  return big ? head_launch_v<1, 4, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream)
+             : head_launch_v<1, 4, T, 8>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
 }
 
 int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,

@@ -910,13 +910,15 @@ def test_conv_pair_is_one_launch_and_bit_identical(dtype):
             L.check(L.load().codon_conv_pair_begin(), "conv_pair_begin")
 
 
-def test_conv_pair_fp32_small_grid():
-    """fp32: the pair form exists for the small-grid kernels (one 64 x 96 image = 96 tiles): one launch, same bits -- plain,
-    chained 1x1 and gated + emitting; a large grid launches at once (two launches)."""
+@pytest.mark.parametrize("hw", [(64, 96), (128, 160)])
+def test_conv_pair_fp32_small_grid(hw):
+    """fp32: the pair form exists for the small-grid kernels: one launch, same bits -- plain, chained 1x1 and gated + emitting.
+    One 64 x 96 image (48 tiles of 4 x 32) pairs the cout-split kernels, one 128 x 160 image (160 tiles) the unsplit ones
+    (against cout-split lone launches).  A large grid launches at once (two launches)."""
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
     dev = _dev()
-    B, H, W = 1, 64, 96
+    B, (H, W) = 1, hw
     q = lambda c, seed: _rand((B, c, H, W), seed).to(dev)
     xa, xb = q(128, 1), q(128, 2)
     wt = lambda co, ci, k, seed, mode=L.PACK_FWD: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), mode, torch.float32)
@@ -957,56 +959,84 @@ def test_conv_pair_fp32_small_grid():
     assert pr.launches == 0                # both launched at once, nothing was held
 
 
+def _unsplit_repeat(B, H, W):
+    """How often a small input has to be repeated along the batch for its launch to leave the cout-split regime (more than 192
+    tiles of 4 x 32) while staying a small grid: the repeated launch runs the UNSPLIT 4 x 32 kernel."""
+    nblk4 = B * ((W + 31) // 32) * ((H + 3) // 4)
+    return 192 // nblk4 + 1
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 96), (1, 37, 70), (2, 33, 40), (1, 1, 1), (1, 128, 128)])
 def test_fp32_cout_split_chained_conv_is_bit_identical(shape):
-    """conv_mfma_f32 CSPLIT (round 5): a lone small-grid conv5x5 128->128 + chained 1x1 runs as 2 x 32 tiles whose four waves are
+    """conv_mfma_f32 CSPLIT (round 5): a small-grid conv5x5 128->128 + chained 1x1 runs as 2 x 32 tiles whose four waves are
     2 rows x 2 cout halves (half the serial MFMA chain per wave; the 1x1's operands meet through LDS).  Every output is the same
-    fma chain in the same order: bit-identical to the unsplit small-grid kernel -- which a one-call pair bracket selects --
-    with and without the residual and the materialised intermediate."""
+    fma chain in the same order: bit-identical to the unsplit small-grid kernel -- which the same images take when they are
+    part of a batch of more than 192 tiles -- with and without the residual and the materialised intermediate; alone, and
+    as one of a pair (codon_conv_pair_begin / _end: one grid of both launches)."""
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
     dev = _dev()
     B, H, W = shape
+    rep = _unsplit_repeat(B, H, W)
     x = _rand((B, 128, H, W), 1).to(dev)
     res = _rand((B, 64, H, W), 2).to(dev)
     w5 = ops.packed_weight(_rand((128, 128, 5, 5), 3, (2.0 / (25 * 128)) ** 0.5).to(dev), L.PACK_FWD, torch.float32)
     w1 = ops.packed_weight(_rand((64, 128, 1, 1), 4, 0.1).to(dev), L.PACK_CHAIN1X1, torch.float32)
+
+    def run(xs, rs, use_res, use_mid, pair):
+        b = xs.shape[0]
+        o = torch.full((b, 128, H, W), float("nan"), device=dev)
+        mid = torch.full((b, 128, H, W), float("nan"), device=dev)
+        with ops.conv_pair(dev, pair) as pr:
+            ops.conv_chain1x1(Slice(xs), w5, w1, Slice(o, 64, 64), mid=Slice(mid) if use_mid else None,
+                              residual=Slice(rs) if use_res else None)
+            if pair:
+                ops.conv_chain1x1(Slice(xs), w5, w1, Slice(o, 0, 64), mid=None, residual=Slice(rs) if use_res else None)
+        assert not pair or pr.launches == 1
+        return o, mid
+
     for use_res, use_mid in ((False, False), (True, False), (True, True)):
-        outs = []
-        for bracket in (False, True):
-            o = torch.full((B, 128, H, W), float("nan"), device=dev)
-            mid = torch.full((B, 128, H, W), float("nan"), device=dev)
-            with ops.conv_pair(dev, bracket) as pr:
-                ops.conv_chain1x1(Slice(x), w5, w1, Slice(o, 64, 64), mid=Slice(mid) if use_mid else None,
-                                  residual=Slice(res) if use_res else None)
-            assert not bracket or pr.launches == 1
-            outs.append((o, mid))
-        assert torch.equal(outs[0][0][:, 64:], outs[1][0][:, 64:]) and torch.isnan(outs[0][0][:, :64]).all()
+        o_u, mid_u = run(x.repeat(rep, 1, 1, 1), res.repeat(rep, 1, 1, 1), use_res, use_mid, False)     # unsplit
+        o_s, mid_s = run(x, res, use_res, use_mid, False)                                               # cout split, alone
+        assert torch.equal(o_u[:B, 64:], o_s[:, 64:]) and torch.isnan(o_s[:, :64]).all()
         if use_mid:
-            assert torch.equal(outs[0][1], outs[1][1])
+            assert torch.equal(mid_u[:B], mid_s)
+        if not use_mid:
+            o_p, _ = run(x, res, use_res, False, True)                                                  # cout split, as a pair
+            assert torch.equal(o_p[:, 64:], o_s[:, 64:]) and torch.equal(o_p[:, :64], o_s[:, 64:])
 
 
 @pytest.mark.parametrize("k,cin,cout", [(5, 64, 64), (3, 64, 64), (3, 128, 64), (3, 64, 128), (5, 128, 128)])
 def test_fp32_cout_split_plain_conv_is_bit_identical(k, cin, cout):
-    """The same split for a lone small-grid plain conv (the trunk's conv8 / conv9 / conv11 at one image per call), every
-    epilogue variant: ReLU, residual, ReLU mask, accumulate, mask of the sum."""
+    """The same split for a small-grid plain conv (the trunk's conv8 / conv9 / conv11 at one image per call, alone; the two
+    streams' convs of a block as a pair), every epilogue variant: ReLU, residual, ReLU mask, accumulate, mask of the sum."""
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
     dev = _dev()
     for (B, H, W) in ((1, 64, 96), (1, 37, 70), (1, 2, 3)):
+        rep = _unsplit_repeat(B, H, W)
         x = _rand((B, cin, H, W), 1).to(dev)
         r = _rand((B, cout, H, W), 2).to(dev)
         prev = _rand((B, cout, H, W), 3).to(dev)
         wp = ops.packed_weight(_rand((cout, cin, k, k), 4, (2.0 / (k * k * cout)) ** 0.5).to(dev), L.PACK_FWD, torch.float32)
-        for kw in (dict(relu=True), dict(residual=Slice(r)), dict(relu_mask=Slice(r)), dict(accumulate=True),
-                   dict(relu_mask=Slice(r), accumulate=True, mask_sum=True)):
-            ys = []
-            for bracket in (False, True):
-                y = prev.clone()
-                with ops.conv_pair(dev, bracket):
-                    ops.conv2d(Slice(x), wp, Slice(y), k, **kw)
-                ys.append(y)
-            assert torch.equal(ys[0], ys[1]), (k, cin, cout, H, W, list(kw))
+        for kw in (dict(relu=True), dict(residual=r), dict(relu_mask=r), dict(accumulate=True),
+                   dict(relu_mask=r, accumulate=True, mask_sum=True)):
+            def run(n, pair):
+                y = prev.repeat(n, 1, 1, 1)
+                y2 = prev.repeat(n, 1, 1, 1)
+                kws = {a: (Slice(v.repeat(n, 1, 1, 1)) if isinstance(v, torch.Tensor) else v) for a, v in kw.items()}
+                with ops.conv_pair(dev, pair) as pr:
+                    ops.conv2d(Slice(x.repeat(n, 1, 1, 1)), wp, Slice(y), k, **kws)
+                    if pair:
+                        ops.conv2d(Slice(x.repeat(n, 1, 1, 1)), wp, Slice(y2), k, **kws)
+                assert not pair or pr.launches == 1
+                return y, y2
+
+            y_u, _ = run(rep, False)              # unsplit (more than 192 tiles)
+            y_s, _ = run(1, False)                # cout split, alone
+            y_p, y_p2 = run(1, True)              # cout split, as a pair
+            assert torch.equal(y_u[:B], y_s), (k, cin, cout, H, W, list(kw))
+            assert torch.equal(y_p, y_s) and torch.equal(y_p2, y_s), (k, cin, cout, H, W, list(kw))
 
 
 def test_fp32_grid_modes_are_bit_identical():
