@@ -655,8 +655,10 @@ def main():
         res = train_leg(model, x, y, dev, dist, rank, world, barrier, a.steps, a.warmup, a.dtype, a.scale, a.scaling,
                         ctrl=ctrl, data=data)
         if rank == 0:
-            for r_, st_ in zip(ranks, res["per_rank_step_ms"]):
+            for r_, st_, hw_ in zip(ranks, res["per_rank_step_ms"], res["per_rank_hwmon"]):
                 r_["train_step_ms"] = st_
+                r_["train_power_w_p50"], r_["train_sclk_mhz_p50"] = hw_["power_w_p50"], hw_["sclk_mhz_p50"]
+                r_["power_cap_w"] = hw_["power_cap_w"]
             res["ranks"], res["versions"] = ranks, versions
             res["backend"] = None if dist is None else ("gloo" if (a.backend == "gloo" or data is not None) else "nccl")
             res["control_backend"] = None if dist is None else "gloo"

@@ -35,13 +35,18 @@ trace() { # trace <label> <stats.csv name> <bench args...>
   find $OUT/${tag}_${label}_trace -name "*kernel_trace.csv" -delete
 }
 
-run bench_default --steps 5 --warmup 2
+# LINES_ONLY=1: only the bench lines (the PMC tables of this library are already in profiles/)
+if [ -z "$LINES_ONLY" ]; then
 trace default ${tag}_default_bench_kernel_stats.csv --steps 3 --warmup 1 --no-cpu-baseline --no-script-pattern
 pmc3 fwd ${tag}_fwd_b32_480x640_pmc.json fwd 4 --no-cpu-baseline --no-fwd-bwd --no-script-pattern
 trace bf16fwd ${tag}_bf16_fwd_b32_480x640_kernel_stats.csv --dtype bf16 --no-cpu-baseline --no-fwd-bwd --steps 3 --warmup 1
 pmc3 bf16fwd ${tag}_bf16_fwd_b32_480x640_pmc.json fwd 2 --dtype bf16 --no-cpu-baseline --no-fwd-bwd
 trace bf16train ${tag}_bf16_train_b32_480x640_kernel_stats.csv --mode train --dtype bf16 --no-cpu-baseline --steps 3 --warmup 1
 pmc3 bf16train ${tag}_bf16_train_b32_480x640_pmc.json train 2 --mode train --dtype bf16 --no-cpu-baseline
+# the lines below read roofline.traffic from profiles/: give them the tables of THIS library (traffic_from_hash == lib_source_hash)
+cp $OUT/${tag}_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_train_b32_480x640_pmc.json $ROOT/profiles/
+fi
+run bench_default --steps 5 --warmup 2
 run bench_bf16 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
 run train_bf16 --mode train --dtype bf16 --steps 10 --warmup 2
 run bench_x8_f32 --scale 8 --batch 16 --height 960 --width 1280 --steps 3 --warmup 1 --no-cpu-baseline --no-fwd-bwd
@@ -49,6 +54,7 @@ run bench_x16_bf16 --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 
 run bench_rmcr_f32 --model rmcr --steps 3 --warmup 1 --no-cpu-baseline
 # one image per call (the reference script's own pattern): kernel statistics + one forward's timeline
 cd $ROOT
+test -n "$LINES_ONLY" && { echo done; exit 0; }
 bash tools/probes/trace_b1.sh ${tag}_b1_fp16_370x463 fp16 370 463 > $OUT/${tag}_b1_fp16.log 2>&1
 bash tools/probes/trace_b1.sh ${tag}_b1_fp32_128x128 fp32 128 128 > $OUT/${tag}_b1_fp32.log 2>&1
 echo done
