@@ -20,6 +20,7 @@ OK = 0
 F32, BF16, F16 = 0, 1, 2
 CONV_RELU, CONV_ADD_RESIDUAL, CONV_ACCUM_OUT, CONV_MASK_RELU, CONV_F16X3, CONV_MASK_SUM = 1, 2, 4, 8, 16, 32
 PACK_FWD, PACK_DGRAD, PACK_FWD_F16X3, PACK_CHAIN1X1, PACK_CHAIN1X1_F16X3 = 0, 1, 2, 3, 4
+TILING_8X32, TILING_4X32, TILING_4X32_SOLO, TILING_2X32_COUT_SPLIT = 0, 1, 2, 3      # codon_conv_tiling_f32
 CAC_FOLDS = 16   # CODON_CAC_FOLDS
 
 
@@ -116,6 +117,7 @@ SIGNATURES = {
     "codon_cac_bwd_reduce_acc": (C.c_int, [_I, _I, _I, _TP, _TP, _TP, _TP, _P, _P, _P, _P, _P, _P, _P, _P, _TP, _TP, _I, _I, _P]),
     "codon_conv_pair_begin": (C.c_int, []),
     "codon_conv_pair_end": (C.c_int, [_P]),
+    "codon_conv_tiling_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int]),
     "codon_cast_multi": (C.c_int, [C.POINTER(CastDesc), _P, _P]),
     "codon_reduce_multi": (C.c_int, [C.POINTER(ReduceItem), _I, _P]),
     "codon_weight_checksum_workspace_bytes": (_S, []),

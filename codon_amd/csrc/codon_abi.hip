@@ -61,6 +61,7 @@ int cac_tail_fwd(int, int, int, int, const float*, const float*, const float*, c
 int cac_fused_finish(int, int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, const float*, const float*, float*, float*,
                    hipStream_t);
+int conv_tiling_f32(const codon_conv_desc*, int, int);
 int conv_chain1x1_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, const codon_tensor*,
                           const codon_tensor*, hipStream_t);
 bool conv_f32x3_supported(const codon_conv_desc*);
@@ -536,6 +537,11 @@ int codon_conv_pair_end(codon_stream_t stream) {
     if (st != CODON_OK) return st;
   }
   return n;
+}
+
+int codon_conv_tiling_f32(const codon_conv_desc* d, int chained, int in_pair) {
+  CODON_REQUIRE(d && shape_ok(d->batch, d->height, d->width), CODON_ERR_BAD_ARG, "conv_tiling_f32: null descriptor or bad shape");
+  return conv_tiling_f32(d, chained, in_pair);
 }
 
 int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream) {

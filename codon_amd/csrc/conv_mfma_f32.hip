@@ -744,6 +744,20 @@ static int launch_conv(const codon_conv_desc* d, const float* x, const float* w,
 
 int conv_ck(int ks) { return ks == 1 ? 16 : 8; }
 
+// codon_conv_tiling_f32 (include/codon_hip.h): the tiling the launchers above give a plain (chained = 0) / chained fp32 conv
+// of this shape outside / inside a pair bracket -- the same rule, restated without a launch (host code only)
+int conv_tiling_f32(const codon_conv_desc* d, int chained, int in_pair) {
+  const bool k5 = d->ksize == 5;
+  const GridMode mode = chained ? grid_mode(d, GRID_SOLO_CHAIN)
+                        : k5    ? grid_mode(d, GRID_SOLO_CONV64) : small_grid(d) ? GRID_4X32_SOLO : GRID_8X32;
+  if (mode == GRID_8X32) return CODON_TILING_8X32;
+  if (mode == GRID_4X32) return CODON_TILING_4X32;
+  const bool splittable = chained || (d->cout % 64 == 0 && d->ksize != 1);
+  const long nblk4 = (long)((d->width + 31) / 32) * ((d->height + 3) / 4) * d->batch;
+  if (splittable && nblk4 <= (in_pair ? CSPLIT_PAIR_MAX_BLOCKS : CSPLIT_MAX_BLOCKS)) return CODON_TILING_2X32_COUT_SPLIT;
+  return CODON_TILING_4X32_SOLO;
+}
+
 template <int KS, int CIN, int COUT, int PSEG>
 static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
                           const float* sp, const float* w, float* y, const codon_tensor* gated_out, bool solo,

@@ -174,6 +174,19 @@ int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t nti
 int codon_conv_pair_begin(void);
 int codon_conv_pair_end(codon_stream_t stream);
 
+/* Which tiling the fp32 conv entry points give a launch of this shape -- a host-side restatement of the launch rule (no GPU
+ * call, nothing is launched): diagnostics, and the CPU tests that pin the rule.  `chained`: codon_conv_chain1x1_fwd
+ * (conv5x5 128->128 + 1x1) instead of codon_conv2d_fwd; `in_pair`: as inside a codon_conv_pair_begin / _end bracket.
+ * A launch of a few rounds of workgroups is priced by its rounds (256 CUs, two 4-wave workgroups per CU):
+ * 8 x 32 pixel tiles two per CU, 4 x 32 two per CU, 4 x 32 one per CU, or (small launches) 2 x 32 with the couts split
+ * over the waves.  Every tiling computes every output pixel with the same fma chain: results do not depend on it.
+ * Replaces nothing in the reference (eager PyTorch leaves tiling to cuDNN: /root/reference/CODON_X4/CODON_x4.py:75-84). */
+#define CODON_TILING_8X32 0
+#define CODON_TILING_4X32 1
+#define CODON_TILING_4X32_SOLO 2
+#define CODON_TILING_2X32_COUT_SPLIT 3
+int codon_conv_tiling_f32(const codon_conv_desc* desc, int chained, int in_pair);
+
 /* A conv whose input is the CAC gate-apply of the producing block, formed while the input tile is staged instead of
  * being written to HBM and read back (inference):   x = pre * (ch * sp) + inputs ,  y = conv(x) [ReLU]
  *   out*ad_CAC + inputs  /  out_c*ad_CAC + inputs_c  feeding conv1, conv2 / conv4, conv5 / conv7

@@ -47,6 +47,36 @@ def test_host_arg_helpers_without_gpu():
     assert b"null pointer" in lib.codon_last_error_string()
 
 
+def test_fp32_launch_rule_without_gpu():
+    """codon_conv_tiling_f32 restates the fp32 launch rule on the host (csrc/conv_mfma_f32.hip grid_mode): a
+    launch of a few rounds of workgroups is priced by its rounds -- 256 CUs, two 4-wave workgroups per CU, the last round at
+    its full price -- and takes the cheapest of 8 x 32 two per CU, 4 x 32 two per CU, 4 x 32 one per CU; below 384 tiles of
+    8 x 32 it is the small-grid mode (4 x 32 one per CU, or 2 x 32 cout-split up to 192 tiles alone / 128 per launch of a pair)."""
+    import ctypes as C
+    from codon_amd import _lib as L
+    lib = L.load()
+
+    def t(B, H, W, k=5, ci=128, co=128, chained=1, pair=0):
+        d = L.ConvDesc(B, H, W, ci, co, k, ci, 0, co, 0, 0, 0, 0, L.F32)
+        return lib.codon_conv_tiling_f32(C.byref(d), chained, pair)
+
+    assert t(32, 480, 640) == L.TILING_8X32                       # the headline batch: 75 rounds, 8 x 32 wins by its 1.4 %
+    assert t(16, 960, 1280) == L.TILING_8X32 and t(8, 1920, 2560) == L.TILING_8X32
+    assert t(1, 370, 463) == L.TILING_4X32                        # 705 tiles: 2 pair rounds of 8 x 32 (3.945 each) vs 3 of 4 x 32 (2 each)
+    assert t(1, 300, 463) == L.TILING_4X32_SOLO                   # 570 tiles: 5 solo rounds (1.093 each) beat 3 x 2 and 2 x 3.945
+    assert t(5, 370, 463) == L.TILING_8X32                        # 3 525 tiles: 7 x 3.945 = 27.6 < 14 x 2
+    assert t(1, 480, 640) == L.TILING_4X32 and t(1, 440, 463) == L.TILING_4X32_SOLO and t(1, 480, 463) == L.TILING_8X32
+    assert t(1, 247, 343) == L.TILING_4X32_SOLO                   # 341 tiles of 8 x 32: small-grid mode, 682 tiles of 4 x 32
+    assert t(1, 128, 128) == L.TILING_2X32_COUT_SPLIT and t(1, 128, 128, pair=1) == L.TILING_2X32_COUT_SPLIT
+    assert t(1, 128, 160) == L.TILING_2X32_COUT_SPLIT and t(1, 128, 160, pair=1) == L.TILING_4X32_SOLO     # 160 tiles: > 128 per pair launch
+    assert t(1, 128, 200) == L.TILING_4X32_SOLO                   # 224 tiles of 4 x 32 > 192
+    # plain convs: 5x5 by the same pricing (its own solo constant), 3x3 / 1x1 only small-grid or not
+    assert t(1, 370, 463, 5, 64, 64, 0) == L.TILING_4X32 and t(32, 480, 640, 5, 64, 64, 0) == L.TILING_8X32
+    assert t(1, 370, 463, 3, 64, 64, 0) == L.TILING_8X32 and t(1, 128, 128, 3, 64, 64, 0) == L.TILING_2X32_COUT_SPLIT
+    assert t(1, 128, 128, 1, 128, 64, 0) == L.TILING_4X32_SOLO    # the 1x1 conv has no cout-split form
+    assert lib.codon_conv_tiling_f32(None, 0, 0) == -1 and b"conv_tiling_f32" in lib.codon_last_error_string()
+
+
 def test_module_surface_matches_reference_contract(golden_dir):
     from codon_amd import CODONNet, CODONNet16
     ref = {}

@@ -1042,7 +1042,7 @@ def test_fp32_cout_split_plain_conv_is_bit_identical(k, cin, cout):
 def test_fp32_grid_modes_are_bit_identical():
     """conv_mfma_f32 grid_mode (round 5): a launch of a few rounds of workgroups picks 8 x 32 tiles, 4 x 32 tiles two per CU or
     4 x 32 tiles one per CU by a cost model of its rounds.  At 300 x 463 one image is priced onto 4 x 32 one-per-CU for the
-    chained conv, at 370 x 463 onto 4 x 32 two-per-CU, and five such images onto 8 x 32: every image of the batch must come
+    chained conv (five of them onto 4 x 32 two-per-CU), at 370 x 463 onto 4 x 32 two-per-CU (five onto 8 x 32): every image of the batch must come
     out with the bits it gets on its own -- plain 5x5 (all epilogues that the one-image forward and backward use), gated +
     emitting, and chained 1x1 with and without residual."""
     from codon_amd import _lib as L, ops
@@ -1051,6 +1051,10 @@ def test_fp32_grid_modes_are_bit_identical():
     W = 463
     wt = lambda co, ci, k, seed, mode=L.PACK_FWD: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), mode, torch.float32)
     w5, w1, w564 = wt(128, 128, 5, 1), wt(64, 128, 1, 2, L.PACK_CHAIN1X1), wt(64, 64, 5, 3)
+    import ctypes as C
+    tiling = lambda b, h: L.load().codon_conv_tiling_f32(C.byref(L.ConvDesc(b, h, W, 128, 128, 5, 128, 0, 128, 0, 0, 0, 0, L.F32)), 1, 0)
+    assert (tiling(1, 300), tiling(1, 370), tiling(5, 300), tiling(5, 370)) == \
+        (L.TILING_4X32_SOLO, L.TILING_4X32, L.TILING_4X32, L.TILING_8X32)      # the premise: one image and five take different tilings
     for H in (300, 370):
         B = 5
         x = _rand((B, 128, H, W), 4).to(dev)
