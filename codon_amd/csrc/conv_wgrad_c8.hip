@@ -310,13 +310,20 @@ __global__ __launch_bounds__(Wc8Waves<KS>::value * 64, KS == 1 ? 2 : 3) void con
       const bool ok = grc[k] >= 0 && gy_ < H && gx_ < W;
       gv[k] = c8_ld(gr, ok ? grel[k] : C8_OOB, 0);
       if constexpr (GB) {
-        const long q = ok ? (long)gy_ * W + gx_ : 0;          // unconditional loads from a valid address, masked below
-        const long bq = (long)b * HW + q;
-        m_sp[k] = p.gb_sp[bq];
-        m_cmax[k] = p.gb_gpooled[(long)b * 2 * HW + q];
-        m_mean[k] = p.gb_gpooled[(long)b * 2 * HW + HW + q] * (1.f / 128.f);
-        m_arg[k] = p.gb_argch[bq];
-        m_pix[k] = ok ? (int)q : -1;
+        // a thread's elements are NT apart and a plane of the tile is TW * TH elements: when that divides NT they are all the
+        // SAME pixel (of different 8-channel planes), whose maps are loaded once -- four loads per tile instead of four per plane
+        constexpr bool SAME_PIXEL = NT % (TW * TH) == 0 && NGE % NT == 0;
+        if (k == 0 || !SAME_PIXEL) {
+          const long q = ok ? (long)gy_ * W + gx_ : 0;        // unconditional loads from a valid address, masked below
+          const long bq = (long)b * HW + q;
+          m_sp[k] = p.gb_sp[bq];
+          m_cmax[k] = p.gb_gpooled[(long)b * 2 * HW + q];
+          m_mean[k] = p.gb_gpooled[(long)b * 2 * HW + HW + q] * (1.f / 128.f);
+          m_arg[k] = p.gb_argch[bq];
+          m_pix[k] = ok ? (int)q : -1;
+        } else {
+          m_sp[k] = m_sp[0]; m_cmax[k] = m_cmax[0]; m_mean[k] = m_mean[0]; m_arg[k] = m_arg[0]; m_pix[k] = m_pix[0];
+        }
       }
     }
   };
