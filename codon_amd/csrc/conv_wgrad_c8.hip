@@ -26,13 +26,14 @@
 namespace codon {
 
 constexpr int WC8_TH = 4;
-// k = 5 (round 5): a staged tile is 8 rows x 32 pixels.  Its x halo is 12 rows for 8 (1.5x) instead of 8 for 4 (2x): the HBM
-// traffic of a 128 -> 128 launch fell from 7.60 to 6.34 GB (1.51x -> 1.26x its 5.03 GB algorithmic bytes, PMC), 5.92 -> 5.72 ms
-// stand-alone, matrix pipe 75 -> 79 % busy at 1.71 -> 1.67 GHz (the kernel runs at the socket's power cap: bytes not moved come
-// back as issue slots).  TWO buffers of twice the size (122 KB of LDS) instead of three: the DMA of tile t+2 still has two
-// 4-row tile times to land, and there are half as many publishing barriers.  (4 rows with three buffers: -DCODON_WC8_TH5=4.)
+// k = 5 (round 5): a staged tile is 10 rows x 32 pixels.  Its x halo is 14 rows for 10 (1.4x) instead of 8 for 4 (2x): the HBM
+// traffic of a 128 -> 128 launch fell from 7.60 GB (4 rows) to 6.34 (8 rows) to 6.07 GB (10 rows) = 1.51x -> 1.26x -> 1.21x
+// its 5.03 GB algorithmic bytes (PMC), 5.92 -> 5.72 -> 5.66 ms stand-alone; at 8 rows the matrix pipe went 75 -> 79 % busy at
+// 1.71 -> 1.67 GHz (the kernel runs at the socket's power cap: bytes not moved come back as issue slots).  TWO buffers
+// (2 x 73 KB of LDS at 10 rows; 12 rows would need 171 KB) instead of the three of the 4-row form: the DMA of tile t+2 still
+// has two 4-row tile times to land, and there are fewer publishing barriers.  (-DCODON_WC8_TH5=8 / =4: the earlier forms.)
 #ifndef CODON_WC8_TH5
-#define CODON_WC8_TH5 8
+#define CODON_WC8_TH5 10
 #endif
 #ifndef CODON_WC8_TH3
 #define CODON_WC8_TH3 6          // k = 3 (round 5): an 8-row halo for 6 rows (1.33x) instead of 6 for 4 (1.5x), 125 KB of LDS: 0.74 -> 0.72 ms; 4 = A/B
