@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import codon_oracle as orc
-from tests.util import BF16_REF_CASES, GOLDEN_CASES, load_case, rel_rmse, rmse
+from tests.util import BF16_REF_CASES, FP16_REF_CASES, GOLDEN_CASES, load_case, rel_rmse, rmse
 
 RMSE_TOL = 1e-4
 
@@ -86,10 +86,14 @@ def test_forward_at_the_reference_scripts_image_sizes(shape):
     with torch.no_grad():
         o = m(x.cuda(), y.cuda())
     assert rmse(o.cpu(), ref) <= RMSE_TOL and rel_rmse(o.cpu(), ref) <= 2e-5
+    # the script's precision at these sizes: 1.25 x the reference module's OWN fp16 error (1.163e-3 from its fp64 run at
+    # 370 x 463, tests/golden/fp16ref_he2_x4_1x370x463.npz; 1.0e-3 ... 1.44e-3 over the fp16ref fixtures) -- against the
+    # fp32 oracle here, whose own distance from fp64 (1e-5) is noise at this level.  The ratio test proper, against the
+    # recorded fp64 output, is test_forward_half_vs_reference_module_run_in_half.
     mh = _model("x4", sd).half()
     with torch.no_grad():
         oh = mh(x.cuda().half(), y.cuda().half())
-    assert rel_rmse(oh.float().cpu(), ref) <= 6e-3
+    assert rel_rmse(oh.float().cpu(), ref) <= 1.25 * 1.44e-3
 
 
 def test_batch_independence_and_determinism():
@@ -190,8 +194,10 @@ def test_forward_half_like_reference_script(name):
     with torch.no_grad():
         o = m(x.cuda().half(), y.cuda().half())
     assert o.dtype == torch.float16 and o.shape == x.shape
-    # fp16 has 11 significand bits: ~8x tighter than bf16
-    assert rel_rmse(o.float().cpu(), z["out_fp64"]) <= 6e-3
+    # fp16 has 11 significand bits: ~8x tighter than bf16.  The bound is 1.25 x the LARGEST error the reference module
+    # itself shows when run with .half() on CPU (1.44e-3, fp16ref_* fixtures); the cases that have such a fixture are
+    # held to their own recorded error in test_forward_half_vs_reference_module_run_in_half
+    assert rel_rmse(o.float().cpu(), z["out_fp64"]) <= 1.25 * 1.44e-3
     # test.py:66,125 calls model(...) in eval mode WITHOUT torch.no_grad(): served by the inference schedule,
     # detached, bit-identical to the no_grad call; in train mode fp16 is refused, not silently wrong
     import warnings
@@ -202,6 +208,34 @@ def test_forward_half_like_reference_script(name):
     m.train()
     with pytest.raises(NotImplementedError):
         m(x.cuda().half(), y.cuda().half())
+
+
+@pytest.mark.parametrize("name", FP16_REF_CASES)
+def test_forward_half_vs_reference_module_run_in_half(name):
+    """Round 6: the reference nn.Module after `.half()` on `.half()` inputs, run on CPU (tools/make_golden_r2.py) -- the
+    only precision /root/reference/CODON_X4/test.py:52,122-125 ever runs -- is itself 1.0e-3 ... 1.44e-3 from its fp64
+    run.  The HIP fp16 path (fp16 storage, fp32 accumulate) must be (a) no further from fp64 than 1.25 x the reference's
+    OWN fp16 error on the same case and (b) within 2.5 x that of the reference's fp16 output (two independent fp16
+    roundings of the same quantity differ by ~sqrt(2) x one)."""
+    z, variant, sd, x, y = load_case(name)
+    assert len(FP16_REF_CASES) == 4
+    m = _model(variant, sd).half()
+    with torch.no_grad():
+        o = m(x.cuda().half(), y.cuda().half())
+    assert o.dtype == torch.float16
+    o = o.float().cpu()
+    ref16 = z["out_fp16"].astype(np.float32)
+    ref_err = rel_rmse(ref16, z["out_fp64"])
+    our_err = rel_rmse(o, z["out_fp64"])
+    print(f"{name}: HIP fp16 vs fp64 {our_err:.3e}, reference fp16 vs fp64 {ref_err:.3e}, ratio {our_err / ref_err:.3f}")
+    assert 5e-4 < ref_err < 3e-3
+    assert our_err <= 1.25 * ref_err, (our_err, ref_err)
+    assert rel_rmse(o, ref16) <= 2.5 * ref_err
+    # fp32 master weights + fp16 compute is at least as close
+    m2 = _model(variant, sd).set_compute_dtype(torch.float16)
+    with torch.no_grad():
+        o2 = m2(x.cuda(), y.cuda()).cpu()
+    assert rel_rmse(o2, z["out_fp64"]) <= 1.25 * ref_err
 
 
 def test_hipgraph_replay_equals_eager():

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import codon_oracle as orc
-from tests.util import BF16_GRAD_CASES, GOLDEN_CASES, load_case, rel_rmse, rmse, target_for
+from tests.util import BF16_GRAD_CASES, FP16_REF_CASES, GOLDEN_CASES, load_case, rel_rmse, rmse, target_for
 
 # fp32 tolerance: the reference's own fp32-vs-fp64 floor is 1.2e-5 RMSE on He-init
 # outputs of std ~5; the restatement uses the same ATen ops, so it
@@ -103,6 +103,23 @@ def test_fp64_and_bf16_autograd_match_reference_fixture(name):
             if v == 0:
                 assert rel_rmse(got_b, z["gbf16." + k]) <= 1e-6, k
             assert 1e-3 < float(z[f"v{v}.err_full.{k}"]) < 0.6, (v, k)      # bf16: 3e-3 ... 4.5e-1 per tensor in the reference itself
+
+
+@pytest.mark.parametrize("name", [n for n in FP16_REF_CASES if "370x463" not in n])
+def test_oracle_in_fp16_reproduces_the_reference_modules_half_run(name):
+    """tools/make_golden_r2.py (round 6): the reference module after `.half()` on half inputs, CPU -- what
+    /root/reference/CODON_X4/test.py:52,122-125 runs.  The oracle is the same ATen ops in the same order, so run in
+    float16 it reproduces that output, and the fixture's fp32 / fp64 outputs pin it as the others do."""
+    z, variant, sd, x, y = load_case(name)
+    assert len(FP16_REF_CASES) == 4
+    with torch.no_grad():
+        o32 = orc.forward(sd, x, y)
+        oh = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half())
+    assert oh.dtype == torch.float16
+    assert rmse(o32, z["out"]) <= RMSE_TOL and rmse(o32, z["out_fp64"]) <= 2e-5
+    assert rel_rmse(oh.float(), z["out_fp16"].astype(np.float32)) <= 1e-6
+    ref_err = rel_rmse(z["out_fp16"].astype(np.float32), z["out_fp64"])
+    assert 5e-4 < ref_err < 3e-3, ref_err          # the reference's own fp16 error: 1.0e-3 ... 1.4e-3
 
 
 def test_state_dict_contract(golden_dir):

@@ -13,7 +13,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.split("_")[0] in ("kat0", "he0", "he1", "he2"))
 # the reference MODULE run in bfloat16 on CPU (tools/make_golden_r2.py): pins the bf16 tolerance
 BF16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16ref_") and f.endswith(".npz"))
-
+# the reference MODULE cast with .half() and run on CPU (tools/make_golden_r2.py, round 6): the reference script's own
+# precision (/root/reference/CODON_X4/test.py:52,122-125)
+FP16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("fp16ref_") and f.endswith(".npz"))
 
 # the reference MODULE run forward AND backward in bfloat16 on CPU + its float64 twin (tools/make_golden_r4.py)
 BF16_GRAD_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16grad_") and f.endswith(".npz"))

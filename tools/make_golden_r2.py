@@ -8,6 +8,10 @@ runs only in the build container, writes data only).  The round-1 fixtures are l
   bf16ref_*         the reference MODULE cast to bfloat16 and run on CPU (net.bfloat16()(x.bfloat16(), y.bfloat16())):
                      pins the bf16 tolerance of the HIP bf16 path to the reference's own bf16 behaviour, beside
                      the fp64 output of the same net
+  fp16ref_*         (round 6) the same for float16 -- the ONLY precision the reference script runs
+                     (/root/reference/CODON_X4/test.py:52,122-125: model.cuda().half(), inputs .half()): the module
+                     cast with .half() and run on CPU, beside its fp32 and fp64 outputs; the three bf16ref shapes plus
+                     one image of the script's own size (Middlebury "Art", 370 x 463)
 """
 import os
 import sys
@@ -33,6 +37,12 @@ BF16_CASES = [
     ("bf16ref_he0_x4_2x24x20", "x4", "he", (2, 24, 20)),
     ("bf16ref_he1_x4_1x40x56", "x4", "he1", (1, 40, 56)),
     ("bf16ref_he0_x16_1x33x9", "x16", "he", (1, 33, 9)),
+]
+FP16_CASES = [
+    ("fp16ref_he0_x4_2x24x20", "x4", "he", (2, 24, 20)),
+    ("fp16ref_he1_x4_1x40x56", "x4", "he1", (1, 40, 56)),
+    ("fp16ref_he0_x16_1x33x9", "x16", "he", (1, 33, 9)),
+    ("fp16ref_he2_x4_1x370x463", "x4", "he2", (1, 370, 463)),
 ]
 
 
@@ -85,6 +95,26 @@ def main():
         np.savez_compressed(os.path.join(mg.GOLD, name + ".npz"), **rec)
         e = float((ob.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
         print(f"{name}: reference bf16-vs-fp64 rel-RMSE {e:.3e}")
+
+    for name, variant, wkind, (B, H, W) in FP16_CASES:
+        net = net_for(variant)
+        sd = orc.he_state(variant, seed=SEEDS[wkind])
+        x, y = orc.kat_inputs(B, H, W)
+        net.float()
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        with torch.no_grad():
+            o32 = net(x, y)
+            o64 = net.double()(x.double(), y.double())
+            oh = net.half()(x.half(), y.half())          # test.py:52 + :122-123 on the CPU
+        net.float()
+        net.load_state_dict(sd, strict=True)        # undo the fp16 rounding of the parameters
+        assert oh.dtype == torch.float16
+        rec = {"shape": np.array([B, H, W]), "variant": variant, "weights": wkind, "out": o32.numpy(),
+               "out_fp64": o64.numpy(), "out_fp16": oh.numpy()}
+        np.savez_compressed(os.path.join(mg.GOLD, name + ".npz"), **rec)
+        e = float((oh.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
+        print(f"{name}: reference fp16-vs-fp64 rel-RMSE {e:.3e}")
 
 
 if __name__ == "__main__":
