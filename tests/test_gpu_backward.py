@@ -292,6 +292,7 @@ def test_bf16_training_gradients_vs_fp32_oracle():
 
 BF16_GRAD_RATIO = 1.25      # the rule test_forward_bf16_vs_reference_module_run_in_bf16 uses for the forward
 BF16_NOISE_FLOOR = 0.10     # pooled reference-bf16 error at which a tensor's bf16 gradient has < 1 significant digit
+BF16_NOISY_RATIO = 1.6      # such a tensor: HIP absolute error <= 1.6 x the reference's own absolute bf16 error (round 6; measured 0.86 ... 1.38)
 
 
 @pytest.mark.parametrize("name", BF16_GRAD_CASES)
@@ -311,7 +312,7 @@ def test_bf16_gradients_vs_reference_bf16_autograd(name):
     for mode in ("fp32 master weights + bf16 compute (configs[2])", "whole-module .bfloat16()"):
         m = _model(variant, sd)
         m = m.set_compute_dtype(torch.bfloat16) if mode.startswith("fp32") else m.bfloat16()
-        hip2, ref2, num_h, num_r, den = {}, {}, 0.0, 0.0, 0.0
+        hip2, ref2, habs, rabs, num_h, num_r, den = {}, {}, {}, {}, 0.0, 0.0, 0.0
         for v in range(nv):
             x, y = bf16grad_inputs(v, B, H, W)
             up = torch.from_numpy(z[f"v{v}.upstream"]).cuda()
@@ -333,6 +334,8 @@ def test_bf16_gradients_vs_reference_bf16_autograd(name):
                 e_ref = float(z[f"v{v}.err_sub.{k}"])
                 hip2.setdefault(k, []).append(d2 / n2)
                 ref2.setdefault(k, []).append(e_ref ** 2)
+                habs[k] = habs.get(k, 0.0) + d2                        # squared ABSOLUTE errors, summed over the variants
+                rabs[k] = rabs.get(k, 0.0) + e_ref ** 2 * n2
                 num_h += d2
                 num_r += e_ref ** 2 * n2
                 den += n2
@@ -348,17 +351,22 @@ def test_bf16_gradients_vs_reference_bf16_autograd(name):
               f"(median {float(np.median(list(cac.values()))):.2f}); whole vector HIP {(num_h / den) ** 0.5:.3e} reference "
               f"{(num_r / den) ** 0.5:.3e}")
         # A tensor whose gradient the REFERENCE's own bf16 run gets wrong by >= 10 % (pooled) carries less than one
-        # significant digit in bf16 whoever computes it: a ratio of two such errors is a ratio of noise (measured: the 5x5
-        # spatial-gate weight of block 0 on the 2 x 24 x 20 case -- reference 1.2e-2 ... 2.8e-1 over the variants, pooled
-        # 0.13; the EXACT fp32 HIP path is already 7e-3 from fp64 there, a cancellation of ~1e5).  Those tensors -- at most
-        # two per case -- are held to "not garbage" (pooled error <= 1) and listed; all others to the ratio.
+        # significant digit in bf16 whoever computes it (measured: the 5x5 spatial-gate weight of block 0 on the 2 x 24 x 20
+        # case -- reference 1.2e-2 ... 2.8e-1 over the variants, pooled 0.13; the EXACT fp32 HIP path is already 7e-3 from
+        # fp64 there, a cancellation of ~1e5).  The pooled RELATIVE error of such a tensor is set by the one variant whose
+        # true gradient happens to cancel furthest (1 / |g64|^2 weights), i.e. by one noise sample of each side; its
+        # ABSOLUTE error is a statistic over every variant and element.  Round 6: those tensors -- at most two per case --
+        # are held to BF16_NOISY_RATIO x the reference's own error in that absolute measure (both sides' squared errors
+        # vs fp64 summed over the variants; measured 0.86 / 1.18 and 1.14 / 1.38 in the two modes); no absolute bound is left.
         noisy = {k for k in ratios if np.mean(ref2[k]) ** 0.5 >= BF16_NOISE_FLOOR}
         if noisy:
             print(f"[{name}] {mode}: bf16-noise-dominated in the reference itself (pooled reference error >= "
-                  f"{BF16_NOISE_FLOOR}): " + ", ".join(f"{k} ref {np.mean(ref2[k]) ** 0.5:.2f} HIP {np.mean(hip2[k]) ** 0.5:.2f}"
-                                                       for k in sorted(noisy)))
+                  f"{BF16_NOISE_FLOOR}): " + ", ".join(
+                      f"{k} relative: ref {np.mean(ref2[k]) ** 0.5:.2f} HIP {np.mean(hip2[k]) ** 0.5:.2f}; absolute-error ratio "
+                      f"HIP / ref {(habs[k] / rabs[k]) ** 0.5:.2f}" for k in sorted(noisy)))
         assert len(noisy) <= 2 and all(k.startswith("attention_s") for k in noisy), noisy
-        assert all(np.mean(hip2[k]) ** 0.5 <= 1.0 for k in noisy)
+        for k in noisy:
+            assert (habs[k] / rabs[k]) ** 0.5 <= BF16_NOISY_RATIO, (mode, k, (habs[k] / rabs[k]) ** 0.5)
         bad = {k: round(float(v), 3) for k, v in ratios.items() if k not in noisy and not v <= BF16_GRAD_RATIO}
         assert not bad, (mode, bad)
         assert len(cac) == 25 and len(conv) == 19

@@ -793,6 +793,58 @@ def test_cac_tail_equals_the_separate_launches(shape, fused):
             assert int(counters.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("shape", [(1, 37, 70), (3, 64, 96), (2, 5, 3), (1, 370, 463)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_cac_tail_against_the_oracle_gates(shape, fused):
+    """Round 6: codon_cac_tail_fwd's own oracle anchor (the bit-identity test above compares it with older HIP launches
+    only).  A random Fcat (B,128,H,W) is reduced on the CPU to exactly the operands the launch takes -- per-tile {sum, max}
+    partials (the pixels of an image cut into ntiles groups: the launch folds groups, their geometry is the producer's
+    business), the two per-stream {max, SUM} maps or the finished {max, mean} map -- and the launch's ch / sp must be
+    oracle.cac_channel / oracle.cac_spatial of that Fcat (/root/reference/CODON_X4/CAC_module.py:38-63, 78-94)."""
+    from codon_amd import _lib as L, ops
+    from oracle import codon_oracle as orc
+    dev = _dev()
+    B, H, W = shape
+    nt = ops.cac_fused_tiles(H, W) if fused else ops.cac_stats_tiles(H, W)
+    if not fused and nt > L.CAC_FOLDS:
+        pytest.skip("fp32 path: the one-launch form is used up to CODON_CAC_FOLDS tiles")
+    assert nt <= H * W
+    g = torch.Generator().manual_seed(B * 77 + H)
+    fcat = torch.randn(B, 128, H, W, generator=g) * 1.5 + 0.3            # channels 0..63 colour, 64..127 depth (CODON_x4.py:85)
+    w1, b1 = torch.randn(8, 128, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1
+    w2, b2 = torch.randn(64, 8, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1
+    ws = torch.randn(1, 2, 5, 5, generator=g) * 0.2
+    with torch.no_grad():
+        want_ch = orc.cac_channel(fcat, w1, b1, w2, b2)
+        want_sp = orc.cac_spatial(fcat, ws)
+    flat = fcat.reshape(B, 128, H * W)
+    cuts = np.linspace(0, H * W, nt + 1).astype(np.int64)
+    partials = torch.empty(B, nt, 128, 2)
+    for t in range(nt):
+        seg = flat[:, :, int(cuts[t]):int(cuts[t + 1])]
+        partials[:, t, :, 0] = seg.sum(2)
+        partials[:, t, :, 1] = seg.max(2)[0]
+    stream_map = lambda f: torch.stack((f.max(1)[0], f.sum(1)), 1).contiguous()
+    pooled_ref = torch.stack((fcat.max(1)[0], fcat.mean(1)), 1).contiguous()
+    ch, sp = torch.empty((B, 64), device=dev), torch.empty((B, 1, H, W), device=dev)
+    pools = torch.empty((B, 2, 128), device=dev)
+    folded = torch.empty((B, L.CAC_FOLDS, 128, 2), device=dev)
+    counters = torch.zeros((B,), dtype=torch.int32, device=dev)
+    cu = lambda *ts: [t.to(dev) for t in ts]
+    if fused:
+        pooled = torch.full((B, 2, H, W), float("nan"), device=dev)
+        ops.cac_tail(B, H, W, partials.to(dev), stream_map(fcat[:, :64]).to(dev), stream_map(fcat[:, 64:]).to(dev), pooled, folded,
+                     counters, *cu(w1, b1, w2, b2, ws), ch, sp, pools)
+        assert torch.equal(pooled[:, 0].cpu(), pooled_ref[:, 0])             # the channel max is exact
+        assert rel_rmse(pooled[:, 1].cpu(), pooled_ref[:, 1]) <= 1e-6
+    else:
+        ops.cac_tail(B, H, W, partials.to(dev), None, None, pooled_ref.to(dev), folded, counters, *cu(w1, b1, w2, b2, ws), ch, sp, pools)
+    torch.cuda.synchronize()
+    assert int(counters.abs().sum()) == 0
+    assert rel_rmse(ch.cpu(), want_ch) <= 1e-5 and float((ch.cpu() - want_ch).abs().max()) <= 1e-5
+    assert rel_rmse(sp.cpu(), want_sp) <= 1e-5 and float((sp.cpu() - want_sp).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_small_parameters_as_one_flat_fp32_buffer(dtype):
     """ops.params_f32 (codon_cast_multi): 28 tensors of a model cast to 16 bits -> fp32 in one launch, exact."""

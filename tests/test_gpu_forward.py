@@ -86,14 +86,20 @@ def test_forward_at_the_reference_scripts_image_sizes(shape):
     with torch.no_grad():
         o = m(x.cuda(), y.cuda())
     assert rmse(o.cpu(), ref) <= RMSE_TOL and rel_rmse(o.cpu(), ref) <= 2e-5
-    # the script's precision at these sizes: 1.25 x the reference module's OWN fp16 error (1.163e-3 from its fp64 run at
-    # 370 x 463, tests/golden/fp16ref_he2_x4_1x370x463.npz; 1.0e-3 ... 1.44e-3 over the fp16ref fixtures) -- against the
-    # fp32 oracle here, whose own distance from fp64 (1e-5) is noise at this level.  The ratio test proper, against the
-    # recorded fp64 output, is test_forward_half_vs_reference_module_run_in_half.
+    # the script's precision at these sizes: no further from the fp32 oracle than 1.25 x the ORACLE RUN IN fp16 on the CPU
+    # is -- the oracle in fp16 reproduces the reference module's own .half() run to 1e-6 (tests/test_oracle.py::
+    # test_oracle_in_fp16_reproduces_the_reference_modules_half_run; with these random inputs it sits at 2.7e-3, with the
+    # fixtures' inputs at 1.0-1.4e-3).  The same ratio against RECORDED reference outputs, one of them at 370 x 463:
+    # test_forward_half_vs_reference_module_run_in_half.
+    with torch.no_grad():
+        ref16 = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half()).float()
+    ref_err = rel_rmse(ref16, ref)
     mh = _model("x4", sd).half()
     with torch.no_grad():
         oh = mh(x.cuda().half(), y.cuda().half())
-    assert rel_rmse(oh.float().cpu(), ref) <= 1.25 * 1.44e-3
+    our_err = rel_rmse(oh.float().cpu(), ref)
+    print(f"{shape}: HIP fp16 vs fp32 oracle {our_err:.3e}, oracle-in-fp16 {ref_err:.3e}, ratio {our_err / ref_err:.3f}")
+    assert 5e-4 < ref_err < 5e-3 and our_err <= 1.25 * ref_err, (our_err, ref_err)
 
 
 def test_batch_independence_and_determinism():
@@ -194,10 +200,19 @@ def test_forward_half_like_reference_script(name):
     with torch.no_grad():
         o = m(x.cuda().half(), y.cuda().half())
     assert o.dtype == torch.float16 and o.shape == x.shape
-    # fp16 has 11 significand bits: ~8x tighter than bf16.  The bound is 1.25 x the LARGEST error the reference module
-    # itself shows when run with .half() on CPU (1.44e-3, fp16ref_* fixtures); the cases that have such a fixture are
-    # held to their own recorded error in test_forward_half_vs_reference_module_run_in_half
-    assert rel_rmse(o.float().cpu(), z["out_fp64"]) <= 1.25 * 1.44e-3
+    # fp16 has 11 significand bits: ~8x tighter than bf16.  Bound: 1.25 x the error of the oracle run in fp16 on the CPU
+    # (= the reference module's .half() run to 1e-6, tests/test_oracle.py) on the same case; the cases that have a
+    # RECORDED reference fp16 output are held to it in test_forward_half_vs_reference_module_run_in_half.  One pixel
+    # (kat0_x4_1x1x1: 0.000516, fp16 spacing 4.8e-7 = 9e-4 relative) is one noise sample per side, not a statistic:
+    # there the bound is the reference's own error plus two fp16 spacings.
+    with torch.no_grad():
+        ref16 = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half()).float()
+    ref_err, our_err = rel_rmse(ref16, z["out_fp64"]), rel_rmse(o.float().cpu(), z["out_fp64"])
+    print(f"{name}: HIP fp16 vs fp64 {our_err:.3e}, oracle-in-fp16 {ref_err:.3e}")
+    if x.numel() == 1:
+        assert our_err <= ref_err + 2 * 2.0 ** -11, (our_err, ref_err)
+    else:
+        assert our_err <= 1.25 * ref_err, (our_err, ref_err)
     # test.py:66,125 calls model(...) in eval mode WITHOUT torch.no_grad(): served by the inference schedule,
     # detached, bit-identical to the no_grad call; in train mode fp16 is refused, not silently wrong
     import warnings
