@@ -303,7 +303,7 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
         gs.zero_grad()
         out = model(x, y)
         loss = crit(out.float(), tgt)
-        loss.backward()
+        gs.backward(loss)                # the direct route: the backward's kernels add into the flat all-reduce buffer
         gs.all_reduce_grads()
         opt.step()
         return loss
@@ -491,6 +491,9 @@ def max_over_ranks(v, dist, ctrl=None):
     return float(t.item())
 
 
+EXIT_RCCL_HUNG = 3      # the line was printed, but an RCCL probe thread hung on some rank: not a healthy run
+
+
 def rccl_probe(dist, dev, world, ctrl, timeout_s=None):
     """First RCCL collective of the run: one all-reduce of a single element on the default (RCCL) group -- this is where
     the communicator over xGMI is formed.  Never fatal AND bounded: the forward has no data-path collective, so when RCCL
@@ -499,7 +502,8 @@ def rccl_probe(dist, dev, world, ctrl, timeout_s=None):
     runs on a helper thread that the caller waits for at most CODON_RCCL_PROBE_TIMEOUT_S (default 90 s): a symmetric
     exception, an asymmetric one (the other ranks then wait for the missing peer) and a hang all end at the vote below
     within that time.  All ranks take the same decision (MIN over the control group).  A helper thread still stuck in RCCL
-    is left behind (daemon); main() then leaves through os._exit so that no destructor waits for it."""
+    is left behind (daemon); main() then marks the line `invalid` and leaves through os._exit(EXIT_RCCL_HUNG) so that no
+    destructor waits for it and no driver records the run as healthy."""
     import threading
     timeout_s = float(timeout_s if timeout_s is not None else os.environ.get("CODON_RCCL_PROBE_TIMEOUT_S", "90"))
     t0 = time.perf_counter()
@@ -819,13 +823,19 @@ def main():
                 res["config0_on_gpu"] = config0_gpu_latency(dev)
                 if not a.no_script_pattern:
                     res["script_pattern_on_gpu"] = script_pattern_latency(dev)
+        if probe is not None and probe.get("any_rank_hung"):
+            # a helper thread was still stuck inside an RCCL collective on some rank while the legs were timed --
+            # it may have held CUs.  The line says so and the process exits with EXIT_RCCL_HUNG: a driver that looks at the
+            # exit code alone must not record a healthy run on a node whose fabric hangs.
+            res["invalid"] = ("an RCCL probe thread was stuck in a collective on at least one rank during the timed legs "
+                              f"(rccl_probe.any_rank_hung): timings may be contaminated; exit code {EXIT_RCCL_HUNG}")
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier(group=ctrl)
         if probe is not None and probe.get("any_rank_hung"):
             # a probe thread is still inside RCCL on some rank: no destructor (here or on a peer) may wait for it
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(EXIT_RCCL_HUNG)
         dist.destroy_process_group()
 
 

@@ -91,13 +91,16 @@ class _CodonFn(torch.autograd.Function):
 
 
 def _grad_sink(model):
-    """name -> the parameter's .grad tensor, when a codon_amd.dist.GradSync(direct=True) owns the gradients of this model:
+    """name -> the parameter's .grad tensor, when a codon_amd.dist.GradSync owns the gradients of this model AND the backward
+    runs inside its direct_backward() context (gs.backward(loss)):
     every used parameter's .grad is then an fp32 view of ONE flat buffer, and the backward kernels ADD into those views
     directly (what autograd's AccumulateGrad would do with returned tensors, minus 44 add launches and their traffic).
     None (the ordinary route: gradients are returned to autograd) unless every view is in place."""
     gs = model.__dict__.get("_grad_sink")
     gs = gs() if gs is not None else None
-    if gs is None or not gs.direct:
+    # opt-in per backward call (ADVICE r5): ctx.needs_input_grad is fixed at forward time, so without the context a
+    # torch.autograd.grad(loss, [x]) or loss.backward(inputs=[x]) would add parameter gradients nobody asked for into .grad
+    if gs is None or not gs.direct or gs._armed <= 0:
         return None
     sink = {}
     for (n, p), view_ptr in zip(gs.named, gs.view_ptrs):

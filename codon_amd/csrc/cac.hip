@@ -394,6 +394,7 @@ struct CacTailArgs {
   int H, W, tiles_x, tiles_y, nsp, ntiles, per;
   float inv_hw;
 };
+static_assert(sizeof(CacTailArgs) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 __global__ __launch_bounds__(256) void cac_tail_kernel(const CacTailArgs a) {
   __shared__ float tl[2][SPF_HALO][SPF_PITCH];

@@ -16,6 +16,7 @@ struct CastMultiArgs {
   const void* src[CODON_CAST_MAX];
   int dtype[CODON_CAST_MAX];
 };
+static_assert(sizeof(CastMultiArgs) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 __global__ __launch_bounds__(256) void cast_multi_kernel(const CastMultiArgs a, float* __restrict__ dst) {
   const unsigned total = a.start[a.n];

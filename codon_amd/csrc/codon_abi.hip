@@ -527,13 +527,15 @@ int codon_conv_pair_end(codon_stream_t stream) {
   g_pair.n = 0;
   const PairCall& a = g_pair.call[0];
   const PairCall& b = g_pair.call[1];
+  // one grid only for two calls that were given pair_end's own stream: a caller that issued them on different streams
+  // ordered its other work against THOSE streams
   if (n == 2 && a.pair == b.pair && a.nblk == b.nblk && a.tiles_x == b.tiles_x && a.tiles_y == b.tiles_y &&
-      (long)a.nblk * 2 < (1L << 31)) {
+      a.stream == (hipStream_t)stream && b.stream == (hipStream_t)stream && (long)a.nblk * 2 < (1L << 31)) {
     const int st = a.pair(a.blob, b.blob, (hipStream_t)stream);
     return st == CODON_OK ? 1 : st;
   }
-  for (int k = 0; k < n; ++k) {
-    const int st = g_pair.call[k].single(g_pair.call[k].blob, (hipStream_t)stream);
+  for (int k = 0; k < n; ++k) {          // one by one, each on the stream its call named
+    const int st = g_pair.call[k].single(g_pair.call[k].blob, g_pair.call[k].stream);
     if (st != CODON_OK) return st;
   }
   return n;

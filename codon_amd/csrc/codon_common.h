@@ -11,6 +11,10 @@ namespace codon {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// Kernel arguments travel in a 4 KiB kernarg segment on gfx950: structs passed BY VALUE to a kernel assert against this where
+// they are defined, so that a field added later fails the build, not the launch.
+#define CODON_KERNARG_LIMIT 4096
+
 // Call after a kernel launch; converts a sticky launch error into CODON_ERR_LAUNCH.
 int check_launch(const char* what);
 

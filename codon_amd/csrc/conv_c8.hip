@@ -53,6 +53,7 @@ struct ConvC8Params {
   float* st_part;       // (B, tiles, 128, 2): per tile, per channel { sum, max } (first stage of the pools, :43,47)
   int st_choff;         // 0 = colour stream (Fcat channels 0..63), 64 = depth stream
 };
+static_assert(sizeof(ConvC8Params) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void static_for_c8(F&& f) {
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(cons
 struct ConvC8Pair {
   ConvC8Params a, b;
 };
+static_assert(sizeof(ConvC8Pair) <= CODON_KERNARG_LIMIT, "two parameter blocks passed by value as one kernel argument");
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_c8_pair_kernel(const ConvC8Pair pp) {
   const int nblk = pp.a.nblk;                                       // == pp.b.nblk (checked on the host)
@@ -983,8 +985,9 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   }
   // inside codon_conv_pair_begin / _end the launch is held back: pair_end issues two held launches of the same kernel variant
   // on the same grid as ONE, anything else one by one in the order they came
-  if (pair_hold(p, &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>, &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>))
-    return CODON_OK;
+  if (const int held = pair_hold(p, &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>,
+                                 &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>, stream))
+    return held < 0 ? held : CODON_OK;
   return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>(&p, stream);
 }
 

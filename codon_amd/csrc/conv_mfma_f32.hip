@@ -59,6 +59,7 @@ struct ConvParams {
   float* y2;
   long y2_img, y2_base;
 };
+static_assert(sizeof(ConvParams) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 template <int KS, int CIN>
 struct ConvCfg {
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvPar
 struct ConvPair {
   ConvParams a, b;
 };
+static_assert(sizeof(ConvPair) <= CODON_KERNARG_LIMIT, "two parameter blocks passed by value as one kernel argument");
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_pair_kernel(const ConvPair pp) {
   const unsigned nblk = (unsigned)pp.a.nblk;                       // == pp.b.nblk (checked on the host)
@@ -678,9 +680,9 @@ static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
 // a cout-split launch: held back by an open pair bracket, else alone with a CU per workgroup
 template <int KS, int CIN, int COUT, bool FUSE, int NW>
 static int launch_or_hold_csplit_f32(const ConvParams& p, hipStream_t stream) {
-  if (pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>,
-                &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>))
-    return CODON_OK;
+  if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>,
+                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>, stream))
+    return held < 0 ? held : CODON_OK;
   return launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>(&p, stream);
 }
 // small-grid launches (PSEG = 1) can be held back by an open pair bracket; everything else launches at once
@@ -688,9 +690,9 @@ template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW>
 static int launch_or_hold_f32(const ConvParams& p, bool small, hipStream_t stream) {
   if constexpr (PSEG == 1) {
     if (small) {
-      if (pair_hold(p, &launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>,
-                    &launch_pair_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>))
-        return CODON_OK;
+      if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>,
+                                     &launch_pair_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>, stream))
+        return held < 0 ? held : CODON_OK;
       return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>(&p, stream);
     }
   }

@@ -110,6 +110,7 @@ struct WgradC8Params {
   int gb_fbase;                        // this stream's first Fcat channel: 0 = colour, 64 = depth
   float gb_inv_hw;
 };
+static_assert(sizeof(WgradC8Params) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 // TAG_CI / TAG_CO: the channel shape of the launch, carried in the kernel NAME only (the code reads p.cin / p.cout): the
 // 5x5 weight gradients of the 128 -> 128 and the 64 -> 64 convs run the same code on the same 256-workgroup grid, and

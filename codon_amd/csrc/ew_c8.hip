@@ -604,6 +604,7 @@ int ew_add_mask_c8(int B, int H, int W, int C, const codon_tensor* dst, const co
 struct EwSum4 {
   C8Slice s[4];
 };
+static_assert(sizeof(EwSum4) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 template <class E>
 __global__ __launch_bounds__(256) void ew_sum_mask_c8_kernel(C8Slice dst, EwSum4 src, int nsrc, C8Slice mask, int has_mask,
                                                              int planes, long HW) {

@@ -23,6 +23,7 @@ struct ReduceMultiArgs {
   int first_block[CODON_REDUCE_MAX_ITEMS + 1];
   int n;
 };
+static_assert(sizeof(ReduceMultiArgs) <= CODON_KERNARG_LIMIT, "passed by value: one more field must not push the launch past the kernel-argument limit");
 
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceMultiArgs a) {
   __shared__ float red[256];

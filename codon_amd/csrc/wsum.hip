@@ -24,6 +24,7 @@ struct WsumArgs {
   unsigned nvec[CODON_WSUM_MAX + 1];      // prefix sums of 16-byte vectors per tensor
   const u32x4* data[CODON_WSUM_MAX];
 };
+static_assert(sizeof(WsumArgs) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
 __device__ __forceinline__ unsigned long long wsum_term(unsigned w, unsigned long long i) {
   return ((unsigned long long)w + 0x9E3779B9ull) * (2ull * i + 1ull) * 0x9E3779B97F4A7C15ull;

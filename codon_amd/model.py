@@ -438,6 +438,16 @@ class _CODONBase(nn.Module):
         self._pack_cache.clear()
         g = self.__dict__.get("_wguard")
         if g is not None:
+            # a forward that ran on stale packed weights and has not been reported yet (the trip is seen one call late) must
+            # not be forgotten with the guard's state: wait for the checksum launches enqueued so far and say so
+            if g.states and torch.cuda.is_available():
+                for d in {st[1].device for st in g.states.values()}:
+                    torch.cuda.synchronize(d)
+            if g.tripped():
+                import warnings
+                warnings.warn(_STALE_MSG + " [reported while the packed-weight cache is being invalidated: at least one "
+                              "forward BEFORE this point used stale packed weights and its output is wrong]", RuntimeWarning,
+                              stacklevel=2)
             g.reset()
         return self
 
@@ -466,8 +476,8 @@ class _CODONBase(nn.Module):
         return self
 
     def _apply(self, fn, *a, **k):
-        # weights legitimately replaced: the cache AND a tripped guard go (a stale forward before this point has been
-        # reported or is moot -- the weights it disagreed with no longer exist)
+        # weights legitimately replaced: the cache AND a tripped guard go -- after invalidate_packed() has reported a stale
+        # forward nobody was told about yet (RuntimeWarning: .half() / .to() / load_state_dict themselves are not at fault)
         self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 

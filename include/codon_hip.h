@@ -170,7 +170,11 @@ int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t nti
  * same grid (same shapes, dtype and epilogue kind), else one after the other -- and returns the number of launches issued
  * (>= 0) or a negative codon_status.  The two calls must be independent (neither reads what the other writes).  Calls the
  * pair form does not cover (1x1 convs, the resident-filter conv3x3 of large grids, fp32 convs that are not small-grid)
- * launch at once, as without the bracket.  Same arithmetic per tile: results are bit-identical to separate launches. */
+ * launch at once, as without the bracket.  Same arithmetic per tile: results are bit-identical to separate launches.
+ * Streams: a held call keeps the stream it was given.  The one-grid form is taken only when both held calls named the
+ * stream pair_end is given; otherwise each is launched alone on ITS OWN stream (so work ordered against those streams stays
+ * ordered).  A third call the pair form covers inside one bracket is refused with CODON_ERR_BAD_ARG (launching it at once
+ * would put it ahead of the two held ones); the bracket stays open and pair_end still issues the first two. */
 int codon_conv_pair_begin(void);
 int codon_conv_pair_end(codon_stream_t stream);
 

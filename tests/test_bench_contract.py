@@ -136,8 +136,9 @@ def test_bench_six_ranks_weak_scaling_rehearsal_of_the_eight_gpu_line():
     assert [r["rank"] for r in d["ranks"]] == list(range(6))
     sc = d["rccl_selfcheck"]
     assert d["grad_equal"] is True and sc["ranks"] == 6, (sc.get("worst_rel"), sc.get("error"))
-    # six is not a power of two: fp32 still agrees to summation order, bf16 to bf16 noise (dist.grad_equality_selfcheck)
-    assert sc["worst_rel"]["f32"] <= 2e-5 and sc["worst_rel"]["bf16"] <= sc["tol_bf16"] == 0.15, sc["worst_rel"]
+    # six is not a power of two: the single-process side sums per-image-mean losses, so both sides see the same 16-bit
+    # activation gradients and agree to fp32 summation order in bf16 too (dist.grad_equality_selfcheck)
+    assert sc["worst_rel"]["f32"] <= 2e-5 and sc["worst_rel"]["bf16"] <= sc["tol_bf16"] == 2e-5, sc["worst_rel"]
     fb = d["fwd_bwd"]
     assert fb["rccl_ranks"] == 6 and fb["global_batch"] == 6 and fb["scaling"] == "weak" and fb["allreduce_us"] > 0
     for r in d["ranks"]:

@@ -504,6 +504,23 @@ def test_packed_weight_verification_catches_data_writes(monkeypatch):
         for _ in range(3):
             m(x, x)
         m.check_packed()
+        # a trip nobody has been told about is not lost when the guard is reset -- .half() / .to() /
+        # load_state_dict() / invalidate_packed() right after the stale forward report it (RuntimeWarning) before they reset
+        for remedy in (lambda: m.load_state_dict(m.state_dict()), lambda: m.to("cuda:0", torch.float32).float(),
+                       lambda: m.invalidate_packed()):
+            m(x, x)
+            m.check_packed()
+            m.conv3.weight.data.mul_(0.5)
+            m(x, x)                              # stale; no synchronisation, no further forward
+            with pytest.warns(RuntimeWarning, match="stale packed weights"):
+                remedy()
+            m(x, x)
+            m.check_packed()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")       # and a clean model resets silently
+            m.load_state_dict(m.state_dict())
+            m.invalidate_packed()
         # the debug switch: same-call detection
         m.conv3.weight.data.mul_(0.5)
         monkeypatch.setattr(M, "VERIFY_PACKED", True)

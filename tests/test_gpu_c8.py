@@ -960,6 +960,29 @@ def test_conv_pair_is_one_launch_and_bit_identical(dtype):
     with ops.conv_pair(dev):
         with pytest.raises(RuntimeError, match="already inside a pair"):
             L.check(L.load().codon_conv_pair_begin(), "conv_pair_begin")
+    # a held call keeps ITS stream -- two calls issued on different streams are not merged into one grid on
+    # pair_end's stream but launched one by one, each where its caller ordered it; a third held-eligible call is refused
+    # (it would run ahead of the two held ones) and the first two still leave with pair_end
+    side = torch.cuda.Stream(device=dev)
+    outs = [ops.new_act(B, 128, H, W, dtype, dev).zero_() for _ in range(2)]
+    torch.cuda.synchronize()
+    with ops.conv_pair(dev, True) as pr:
+        ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[0], 64, 64), 5, relu=True)
+        with torch.cuda.stream(side):
+            ops.conv2d(Slice(xb, 64, 64), w5b, Slice(outs[1], 0, 64), 5, relu=True)
+    assert pr.launches == 2
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], o0[0]) and torch.equal(outs[1], o0[1])
+    outs = [ops.new_act(B, 128, H, W, dtype, dev).zero_() for _ in range(3)]
+    with ops.conv_pair(dev, True) as pr:
+        ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[0], 64, 64), 5, relu=True)
+        ops.conv2d(Slice(xb, 64, 64), w5b, Slice(outs[1], 0, 64), 5, relu=True)
+        with pytest.raises(RuntimeError, match="third conv call"):
+            ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[2], 0, 64), 5, relu=True)
+    assert pr.launches == 1
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], o0[0]) and torch.equal(outs[1], o0[1]) and float(outs[2].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("hw", [(64, 96), (128, 160)])

@@ -88,7 +88,7 @@ def _worker(rank, world, port, q):
             m.set_compute_dtype(dt)
             gs.zero_grad()
             out = m(xd[lo:hi], yd[lo:hi])
-            (out - td[lo:hi]).abs().mean().backward()             # per-shard mean: averaging over ranks is exact
+            gs.backward((out - td[lo:hi]).abs().mean())          # per-shard mean: averaging over ranks is exact; direct route
             gs.all_reduce_grads()
             torch.cuda.synchronize(dev)
             if rank == 0:
@@ -191,7 +191,7 @@ def _worker_ragged(rank, world, port, q, B):
             gs.zero_grad()
             out = m(x[lo:hi], y[lo:hi])
             assert out.shape[0] == hi - lo
-            ((out - t[lo:hi]).abs().sum() * (world / t.numel())).backward()
+            gs.backward((out - t[lo:hi]).abs().sum() * (world / t.numel()))
             gs.all_reduce_grads()
             torch.cuda.synchronize(dev)
             if rank == 0:

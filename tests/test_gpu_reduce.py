@@ -91,9 +91,11 @@ def test_deferred_reduce_equals_the_immediate_form_bit_for_bit(dtype):
 @pytest.mark.parametrize("dtype", [None, torch.bfloat16])
 @pytest.mark.parametrize("defer", [True, False])
 def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype, defer):
-    """GradSync(direct=True): the backward kernels add into the .grad views themselves.  Same values as the ordinary
-    route bit for bit (0 + g == g), a second backward accumulates (g + g), and a
-    dropped view (zero_grad(set_to_none=True)) falls back to the ordinary route for that step."""
+    """gs.backward(loss) / `with gs.direct_backward()`: the backward kernels add into the .grad views themselves.  Same values
+    as the ordinary route bit for bit (0 + g == g), a second backward accumulates (g + g), and a dropped view
+    (zero_grad(set_to_none=True)) falls back to the ordinary route for that step.  Outside the context the
+    ordinary route runs: a plain loss.backward() gives the same bits, and torch.autograd.grad / backward(inputs=[x]) write
+    nothing into the flat buffer."""
     from codon_amd import autograd
     from codon_amd.dist import GradSync
     sd = orc.he_state("x4", seed=29)
@@ -108,11 +110,27 @@ def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype
         ref = {k: p.grad.clone() for k, p in m0.named_parameters() if p.grad is not None}
         m = _model(sd, dtype)
         gs = GradSync(m)
-        assert autograd._grad_sink(m) is not None
+        assert autograd._grad_sink(m) is None              # opt-in per backward call
+        with gs.direct_backward():
+            assert autograd._grad_sink(m) is not None
+        assert autograd._grad_sink(m) is None
+        # the ordinary route through a GradSync-owned model: only what was asked for is written
+        gs.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        gx, = torch.autograd.grad((m(xr, y) - tgt).abs().mean(), [xr])
+        assert gx is not None and bool(torch.isfinite(gx).all()) and float(gs.flat.abs().max()) == 0.0
+        (m(xr, y) - tgt).abs().mean().backward(inputs=[xr])
+        assert float(gs.flat.abs().max()) == 0.0 and torch.equal(xr.grad, gx)
+        with gs.direct_backward():                          # ... and the same request inside the context does what it says
+            pass
+        (m(x, y) - tgt).abs().mean().backward()            # plain backward: autograd accumulates into the views
+        bad = [n for n, p in gs.named if not torch.equal(p.grad, ref[n])]
+        assert not bad, bad
+        assert all(p.grad._base is gs.flat for p in gs.params)
         calls = []
         hooks = [p.register_post_accumulate_grad_hook(lambda p_: calls.append(1)) for p in gs.params]
         gs.zero_grad()
-        (m(x, y) - tgt).abs().mean().backward()
+        gs.backward((m(x, y) - tgt).abs().mean())
         torch.cuda.synchronize()
         assert len(calls) == 44                # post-accumulate hooks still fire (AccumulateGrad sees "no gradient": no add)
         names = [n for n, _ in gs.named]
@@ -122,7 +140,7 @@ def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype
         assert all(p.grad._base is gs.flat for p in gs.params)
         # a second backward accumulates: ((g + r_1) + r_2) + ... over the uses of a shared weight -- g + g up to fp32
         # re-association (exactly g + g for the single-use tensors)
-        (m(x, y) - tgt).abs().mean().backward()
+        gs.backward((m(x, y) - tgt).abs().mean())
         bad = [n for n, p in gs.named if rel_rmse(p.grad.cpu(), (ref[n] + ref[n]).cpu()) > 1e-6]
         assert not bad, bad
         assert torch.equal(m.conv7.weight.grad, ref["conv7.weight"] + ref["conv7.weight"])
@@ -133,17 +151,20 @@ def test_gradients_added_into_the_gradsync_buffer_equal_returned_gradients(dtype
             h.remove()
         gs.zero_grad()
         m.conv3.weight.grad = None
-        assert autograd._grad_sink(m) is None
-        (m(x, y) - tgt).abs().mean().backward()
+        with gs.direct_backward():
+            assert autograd._grad_sink(m) is None
+        gs.backward((m(x, y) - tgt).abs().mean())
         gs.all_reduce_grads()
         bad = [n for n, p in gs.named if not torch.equal(p.grad, ref[n])]
         assert not bad, bad
-        assert autograd._grad_sink(m) is not None
+        with gs.direct_backward():
+            assert autograd._grad_sink(m) is not None
         # direct=False never takes the sink
         m2 = _model(sd, dtype)
         gs2 = GradSync(m2, direct=False)
-        assert autograd._grad_sink(m2) is None
-        (m2(x, y) - tgt).abs().mean().backward()
+        with gs2.direct_backward():
+            assert autograd._grad_sink(m2) is None
+        gs2.backward((m2(x, y) - tgt).abs().mean())
         assert all(torch.equal(p.grad, ref[n]) for n, p in gs2.named)
     finally:
         autograd.DEFER_REDUCE = old
