@@ -76,6 +76,7 @@ SIGNATURES = {
     "codon_conv_chain1x1_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P]),
     "codon_conv_chain1x1_stats_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _TP, _TP, _P, _P, _I, _P]),
     "codon_cac_fused_tiles": (_I, [_I, _I]),
+    "codon_cac_fused_parts": (_I, [_I, _I, _I]),
     "codon_cac_fused_finish": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "codon_cac_gate_folded_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "codon_cac_tail_fwd": (C.c_int, [_I, _I, _I, _I] + [_P] * 14 + [_P]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "codon_conv1x1_bwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _TP, _P, _P, C.c_size_t, _I, _P]),
     "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "codon_head_fwd_y16": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_cac_stats_tiles": (_I, [_I, _I]),
     "codon_cac_stats_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _I, _P]),
     "codon_cac_stats_scaled_fwd": (C.c_int, [_I, _I, _I, _TP, _TP, _P, _P, _P, _I, _P]),

@@ -46,7 +46,9 @@ int cast_multi(const codon_cast_desc* d, float* dst, hipStream_t stream) {
   }
   for (int t = d->n; t < CODON_CAST_MAX; ++t) { a.src[t] = nullptr; a.dtype[t] = 0; a.start[t + 1] = a.start[d->n]; }
   const unsigned total = a.start[d->n];
-  hipLaunchKernelGGL(cast_multi_kernel, dim3((total + 255) / 256 < 64 ? (total + 255) / 256 : 64), dim3(256), 0, stream, a, dst);
+  // a few thousand parameter values, or -- a 16-bit model's input images ride along (codon_amd/model.py) -- two images
+  const unsigned blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(cast_multi_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, stream, a, dst);
   return check_launch("cast_multi_kernel");
 }
 

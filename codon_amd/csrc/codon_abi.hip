@@ -63,7 +63,7 @@ int cac_gate_fwd_n(int, int, float, const float*, const float*, const float*, co
                    hipStream_t);
 int conv_tiling_f32(const codon_conv_desc*, int, int);
 int conv_chain1x1_fwd_f32(const codon_conv_desc*, const float*, const float*, float*, const float*, const codon_tensor*,
-                          const codon_tensor*, hipStream_t);
+                          const codon_tensor*, float*, float*, int, hipStream_t);
 bool conv_f32x3_supported(const codon_conv_desc*);
 int conv2d_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const float*, hipStream_t);
 int pack_weight_f32x3(const float*, void*, int, int, int, hipStream_t);
@@ -84,7 +84,7 @@ int cac_bwd_apply(int, int, int, const codon_tensor*, const codon_tensor*, const
 int ew_add_mask(int, int, int, int, const codon_tensor*, const codon_tensor*, const codon_tensor*, int, int,
                 hipStream_t);
 int ew_sum_mask(int, int, int, int, const codon_tensor*, int, const codon_tensor* const*, const codon_tensor*, int, hipStream_t);
-int head_fwd(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
+int head_fwd(int, int, int, const void*, int, int, const float*, const float*, void*, bool, int, hipStream_t);
 int cac_stats_tiles(int, int);
 int cac_stats_fwd(int, int, int, const codon_tensor*, const codon_tensor*, float*, float*, int, hipStream_t, const float*);
 int ew_sq_scale(int, int, int, const codon_tensor*, const float*, const codon_tensor*, int, hipStream_t);
@@ -252,7 +252,7 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
   if (d->flags & CODON_CONV_F16X3)
     return conv_chain1x1_fwd_f32x3(d, (const float*)x, w_packed, (float*)y, w_chain, out, residual, (hipStream_t)stream);
   return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out,
-                               residual, (hipStream_t)stream);
+                               residual, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int codon_conv_chain1x1_stats_fwd(const codon_conv_desc* d, const void* x, const void* w_packed, void* y,
@@ -267,14 +267,29 @@ int codon_conv_chain1x1_stats_fwd(const codon_conv_desc* d, const void* x, const
   CODON_REQUIRE((d->flags & ~CODON_CONV_RELU) == 0, CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: only the RELU flag applies");
   CODON_REQUIRE(((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)w_chain % 16) == 0 && ((uintptr_t)stats_partials % 8) == 0,
                 CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: misaligned buffer");
-  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED,
-                "conv_chain1x1_stats_fwd: 16-bit tensors only (fp32 takes codon_conv_chain1x1_fwd + codon_cac_stats_fwd)");
+  CODON_REQUIRE(d->x_coff >= 0 && d->x_coff + d->cin <= d->x_ctotal && (!y || (d->y_coff >= 0 && d->y_coff + d->cout <= d->y_ctotal)) &&
+                    out->coff >= 0 && out->coff + 64 <= out->ctotal, CODON_ERR_BAD_ARG,
+                "conv_chain1x1_stats_fwd: slice outside its buffer");
+  if (d->dtype == CODON_F32) {
+    // fp32 (round 6): per-row-strip partials, codon_cac_fused_parts(height, width, CODON_F32) rows per image
+    CODON_REQUIRE(!residual, CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: fp32 statistics come without a residual");
+    return conv_chain1x1_fwd_f32(d, (const float*)x, (const float*)w_packed, (float*)y, (const float*)w_chain, out, nullptr,
+                                 stats_pool, stats_partials, stats_choff, (hipStream_t)stream);
+  }
+  CODON_REQUIRE(d->dtype == CODON_BF16 || d->dtype == CODON_F16, CODON_ERR_UNSUPPORTED, "conv_chain1x1_stats_fwd: dtype %d", d->dtype);
   return conv_chain1x1_fwd_16(d, x, w_packed, y, w_chain, out, residual, stats_pool, stats_partials, stats_choff,
                               (hipStream_t)stream);
 }
 
 int32_t codon_cac_fused_tiles(int32_t height, int32_t width) {
   return (height > 0 && width > 0) ? cac_fused_tiles(height, width) : 0;
+}
+
+int32_t codon_cac_fused_parts(int32_t height, int32_t width, int32_t dtype) {
+  if (height <= 0 || width <= 0) return 0;
+  if (dtype == CODON_F32) return height * ((width + 31) / 32);         // one row strip of 32 pixels each
+  if (dtype == CODON_BF16 || dtype == CODON_F16) return cac_fused_tiles(height, width);
+  return 0;
 }
 
 int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const float* partials, const float* pool_c,
@@ -294,7 +309,8 @@ int codon_cac_tail_fwd(int32_t batch, int32_t height, int32_t width, int32_t nti
   CODON_REQUIRE((pool_c != nullptr) == (pool_d != nullptr) && (pool_c || pooled), CODON_ERR_BAD_ARG,
                 "cac_tail_fwd: pool_c and pool_d together, or pooled to read");
   CODON_REQUIRE(shape_ok(batch, height, width) && batch <= 65535, CODON_ERR_BAD_ARG, "cac_tail_fwd: bad shape");
-  CODON_REQUIRE(ntiles == (pool_c ? cac_fused_tiles(height, width) : cac_stats_tiles(height, width)), CODON_ERR_BAD_ARG,
+  CODON_REQUIRE(pool_c ? (ntiles == cac_fused_tiles(height, width) || ntiles == codon_cac_fused_parts(height, width, CODON_F32))
+                       : ntiles == cac_stats_tiles(height, width), CODON_ERR_BAD_ARG,
                 "cac_tail_fwd: ntiles %d does not match the producer of the partials", ntiles);
   return cac_tail_fwd(batch, height, width, ntiles, partials, pool_c, pool_d, pool_c ? nullptr : pooled, pool_c ? pooled : nullptr,
                       folded, counters, w1, b1, w2, b2, w_spatial, ch, pools_out, sp, (hipStream_t)stream);
@@ -419,7 +435,18 @@ int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, 
   CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "head_fwd: bad shape");
   CODON_REQUIRE(x_coff >= 0 && x_coff + 64 <= x_ctotal, CODON_ERR_BAD_ARG, "head_fwd: input slice outside buffer");
   CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "head_fwd: dtype %d", dtype);
-  return head_fwd(batch, height, width, x, x_ctotal, x_coff, w_oihw, residual, y, dtype, (hipStream_t)stream);
+  return head_fwd(batch, height, width, x, x_ctotal, x_coff, w_oihw, residual, y, false, dtype, (hipStream_t)stream);
+}
+
+int codon_head_fwd_y16(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal, int32_t x_coff,
+                       const float* w_oihw, const float* residual, void* y16, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(x && w_oihw && residual && y16, CODON_ERR_BAD_ARG, "head_fwd_y16: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "head_fwd_y16: bad shape");
+  CODON_REQUIRE(x_coff >= 0 && x_coff + 64 <= x_ctotal, CODON_ERR_BAD_ARG, "head_fwd_y16: input slice outside buffer");
+  CODON_REQUIRE((dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED,
+                "head_fwd_y16: dtype %d (the 16-bit output exists for 16-bit activations)", dtype);
+  CODON_REQUIRE(((uintptr_t)y16 % 2) == 0, CODON_ERR_BAD_ARG, "head_fwd_y16: output not 2-byte aligned");
+  return head_fwd(batch, height, width, x, x_ctotal, x_coff, w_oihw, residual, y16, true, dtype, (hipStream_t)stream);
 }
 
 int32_t codon_cac_stats_tiles(int32_t height, int32_t width) {

@@ -58,6 +58,10 @@ struct ConvParams {
   const float* w2;  // [t2][t][lane][16]: W1[t2*32 + (lane&31)][t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
   float* y2;
   long y2_img, y2_base;
+  // FUSE + ST only: CAC statistics of the 64 channels this launch produces, from the epilogue (no pass over the tensor)
+  float* st_pool;   // (B,2,H,W): per pixel { max, SUM } over this stream's 64 channels (ChannelPool, CAC_module.py:81)
+  float* st_part;   // (B, H * tiles_x, 128, 2): per ROW STRIP of 32 pixels, per channel { sum, max } (first stage of the pools, :43,47)
+  int st_choff;     // 0 = colour stream (Fcat channels 0..63), 64 = depth stream
 };
 static_assert(sizeof(ConvParams) <= CODON_KERNARG_LIMIT, "passed by value as a kernel argument");
 
@@ -113,9 +117,16 @@ enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 // of 3200.  Every output is still the same fma chain over k in the same order (a wave owns whole cout tiles), so results are
 // bit-identical to the unsplit kernel; the chained 1x1 needs all 128 intermediate channels of a pixel row, which now sit in
 // two waves: they meet through LDS (free after the last stage) in the accumulator layout, which IS the B operand layout.
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
+// ST (round 6, FUSE only): the epilogue also leaves the CAC statistics of its 64 output channels -- per pixel { max, sum } and
+// per channel { sum, max } over ROW STRIPS of 32 pixels.  A strip's 32 values of a channel sit in the 32 lanes of a half-wave
+// whatever the tile shape (8 x 32, 4 x 32, 2 x 32 cout-split), and are summed by one fixed DPP tree; the strips are folded in
+// index order afterwards (cac_tail_kernel): the statistics -- hence the gates, hence the image -- do not depend on the tiling,
+// i.e. on the batch an image arrives in.  One 128 x 128 image: five 22-us statistics passes per forward gone.
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false,
+          bool ST = false>
 __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid) {
   static_assert(!CSPLIT || (PSEG == 1 && NW == 4 && COUT % 64 == 0 && !GATE), "the cout-split form is a small-grid plain / chained conv");
+  static_assert(!ST || FUSE, "statistics come out of the chained 1x1's epilogue");
   constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
   constexpr int TW = 32, TH = (CSPLIT ? NW / 2 : NW) * PSEG;
@@ -349,6 +360,36 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   const float* const rbase = p.res ? p.res + (long)b * p.r_img + p.r_base : p.x;
   auto inplane = [&](int r) { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW4; };   // cout plane inside a 32-cout tile
 
+  // ST: statistics of one pixel row of one 32-channel output tile (dv: lane = pixel column l31, register r = channel
+  // t2 * 32 + (r&3) + 8(r>>2) + 4 half).  Returns this lane's { sum, max } over its 16 channels (serial in r); stores, per
+  // channel, { sum, max } over the row strip's 32 pixels (off-image columns: 0 / -inf) -- the reduction over the 32 lanes of
+  // a half is five DPP steps whose result stands in lanes 31 and 63.
+  auto half_red = [](float v, auto maxc) {
+    constexpr bool MX = decltype(maxc)::value;
+    auto op = [](float a_, float b_) { return MX ? fmaxf(a_, b_) : a_ + b_; };
+    v = op(v, dpp_take<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = op(v, dpp_take<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = op(v, dpp_take<0x124>(v));           // row_ror:4
+    v = op(v, dpp_take<0x128>(v));           // row_ror:8   -> every lane holds its 16-lane row's result
+    v = op(v, dpp_take<0x142, 0xa>(v));      // row_bcast:15 into rows 1, 3 -> lanes 16..31 / 48..63 hold their half's
+    return v;
+  };
+  auto row_stats = [&](const f32x16& dv, int t2, int gy, bool colok, float& ls, float& lm) {
+    ls = 0.f; lm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ls += dv[r]; lm = fmaxf(lm, dv[r]); }
+    if (gy >= H) return;                     // wave-uniform: no such strip
+    float2* const out = reinterpret_cast<float2*>(p.st_part) +
+                        (((long)b * H + gy) * p.tiles_x + tx) * 128 + p.st_choff + t2 * 32 + 4 * half;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float cs = half_red(colok ? dv[r] : 0.f, std::false_type{});
+      const float cm = half_red(colok ? dv[r] : -INFINITY, std::true_type{});
+      if (l31 == 31) out[(r & 3) + 8 * (r >> 2)] = make_float2(cs, cm);
+    }
+  };
+  (void)half_red; (void)row_stats;
+
   if constexpr (FUSE) {
     // Chained 1x1: the D layout of the 32x32 MFMA (lane = pixel l&31, register r = channel (r&3)+8(r>>2)+4(l>>5))
     // IS a B operand of the next MFMA for the channel pair {c, c+4}: lanes 0-31 carry k = 0, lanes 32-63 k = 1 of
@@ -416,12 +457,32 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
 #pragma unroll
         for (int r = 0; r < 16; ++r) buf_st(d[r], y2r_, vo[0], inplane(r));
       }
+      if constexpr (ST) {
+        // this wave: row wrow, output tile t2.  The pixel's 64 channels sit in the two waves of its row: the per-tile
+        // { sum, max } meet in LDS behind the exchange region, the t2 = 0 wave adds them P[0] + P[1] -- the unsplit order
+        const int gy = ty0 + wrow;
+        float ls, lm;
+        row_stats(d, t2, gy, gx < W, ls, lm);
+        ls += __shfl_xor(ls, 32, 64);
+        lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+        float* const pp = lds + 2 * CTALL * 16 * 64;           // [row][t2][32][2]
+        static_assert(2 * CTALL * 16 * 64 + 256 <= 2 * XSP + 2 * WSP, "the pixel statistics fit behind the exchange");
+        if (half == 0) { pp[((wrow * 2 + t2) * 32 + l31) * 2] = ls; pp[((wrow * 2 + t2) * 32 + l31) * 2 + 1] = lm; }
+        __syncthreads();
+        if (t2 == 0 && half == 0 && vo[0] != BUF_OOB) {
+          const float s1 = pp[((wrow * 2 + 1) * 32 + l31) * 2], m1 = pp[((wrow * 2 + 1) * 32 + l31) * 2 + 1];
+          const long q = (long)gy * W + gx;
+          p.st_pool[(long)b * 2 * HWl + q] = fmaxf(lm, m1);
+          p.st_pool[(long)b * 2 * HWl + HWl + q] = ls + s1;
+        }
+      }
       CODON_TSTAMP(p.dbg, 4)
       return;
     }
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 128 * 4, BUF_FLAGS);
     const float* const y2base = p.y2 + (long)b * p.y2_img + p.y2_base;
     const unsigned w2vo = (unsigned)lane * 64u;
+    float psum[ST ? PSEG : 1], pmax[ST ? PSEG : 1];
 #pragma unroll 1
     for (int t2 = 0; t2 < 2; ++t2) {
       f32x16 d[PSEG];
@@ -460,6 +521,26 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
 #pragma unroll
           for (int r = 0; r < 16; ++r) buf_st(d[i][r], y2rsrc, vo[i], inplane(r));
       }
+      if constexpr (ST) {
+#pragma unroll
+        for (int i = 0; i < PSEG; ++i) {
+          float ls, lm;
+          row_stats(d[i], t2, ty0 + wrow * PSEG + i, gx < W, ls, lm);
+          ls += __shfl_xor(ls, 32, 64);                     // P[t2]: the tile's 32 channels of this pixel
+          lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+          psum[i] = t2 == 0 ? ls : psum[i] + ls;            // P[0] + P[1]
+          pmax[i] = t2 == 0 ? lm : fmaxf(pmax[i], lm);
+        }
+      }
+    }
+    if constexpr (ST) {
+#pragma unroll
+      for (int i = 0; i < PSEG; ++i)
+        if (half == 0 && vo[i] != BUF_OOB) {
+          const long q = (long)(ty0 + wrow * PSEG + i) * W + gx;
+          p.st_pool[(long)b * 2 * HWl + q] = pmax[i];
+          p.st_pool[(long)b * 2 * HWl + HWl + q] = psum[i];
+        }
     }
     CODON_TSTAMP(p.dbg, 4)
     return;
@@ -526,9 +607,10 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   CODON_TSTAMP(p.dbg, 4)
 }
 
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false,
+          bool ST = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_kernel(const ConvParams p) {
-  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>(p, xcd_remap(blockIdx.x, (unsigned)p.nblk));
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT, ST>(p, xcd_remap(blockIdx.x, (unsigned)p.nblk));
 }
 
 // Two convs of one shape and kernel variant as ONE grid of 2 * nblk workgroups (codon_conv_pair_begin / _end): the depth and
@@ -539,12 +621,13 @@ struct ConvPair {
   ConvParams a, b;
 };
 static_assert(sizeof(ConvPair) <= CODON_KERNARG_LIMIT, "two parameter blocks passed by value as one kernel argument");
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false,
+          bool ST = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_pair_kernel(const ConvPair pp) {
   const unsigned nblk = (unsigned)pp.a.nblk;                       // == pp.b.nblk (checked on the host)
   const unsigned v = xcd_remap(blockIdx.x, 2u * nblk);
   const bool second = v >= nblk;                                   // workgroup-uniform
-  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>(second ? pp.b : pp.a, second ? v - nblk : v);
+  conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT, ST>(second ? pp.b : pp.a, second ? v - nblk : v);
 }
 
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
@@ -655,10 +738,10 @@ static unsigned solo_lds_pad() {  // kernels of the same signature, i.e. give ev
 
 // one launch of a filled parameter block / two blocks of the same variant as one grid (pair.h).  `small` launches ask for the
 // solo-LDS padding so that every workgroup has a CU to itself.
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false, bool ST = false>
 static int launch_single_f32(const void* pv, hipStream_t stream) {
   const ConvParams& p = *static_cast<const ConvParams*>(pv);
-  constexpr auto kern = conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>;
+  constexpr auto kern = conv_mfma_f32_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT, ST>;
   const unsigned dyn = SOLO ? solo_lds_pad<kern>() : 0u;
   hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(NW * 64), dyn, stream, p);
   return check_launch(CSPLIT ? "conv_mfma_f32_kernel<cout split>" : "conv_mfma_f32_kernel");
@@ -666,37 +749,37 @@ static int launch_single_f32(const void* pv, hipStream_t stream) {
 // CSPLIT pairs (2 x 32 tiles, couts split over the waves): up to 256 workgroups in all take a CU each; 257 .. 512 run two to
 // a CU with no padding -- each SIMD then holds two waves of half the serial MFMA chain, which hide each other's stage waits
 // (BASELINE configs[0]: the pair of chained convs 225 -> 218 us, of 5x5 64->64 convs 62 -> 57, of 3x3 26 -> 24).
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool SOLO, bool CSPLIT = false, bool ST = false>
 static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
   ConvPair pp;
   pp.a = *static_cast<const ConvParams*>(av);
   pp.b = *static_cast<const ConvParams*>(bv);
-  constexpr auto kern = conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT>;
+  constexpr auto kern = conv_mfma_f32_pair_kernel<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT, ST>;
   const bool solo = SOLO && (!CSPLIT || 2 * pp.a.nblk <= 256);
   const unsigned dyn = solo ? solo_lds_pad<kern>() : 0u;
   hipLaunchKernelGGL(kern, dim3(2u * (unsigned)pp.a.nblk), dim3(NW * 64), dyn, stream, pp);
   return check_launch("conv_mfma_f32_pair_kernel");
 }
 // a cout-split launch: held back by an open pair bracket, else alone with a CU per workgroup
-template <int KS, int CIN, int COUT, bool FUSE, int NW>
+template <int KS, int CIN, int COUT, bool FUSE, int NW, bool ST = false>
 static int launch_or_hold_csplit_f32(const ConvParams& p, hipStream_t stream) {
-  if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>,
-                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>, stream))
+  if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>,
+                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>, stream))
     return held < 0 ? held : CODON_OK;
-  return launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true>(&p, stream);
+  return launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>(&p, stream);
 }
 // small-grid launches (PSEG = 1) can be held back by an open pair bracket; everything else launches at once
-template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW>
+template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool ST = false>
 static int launch_or_hold_f32(const ConvParams& p, bool small, hipStream_t stream) {
   if constexpr (PSEG == 1) {
     if (small) {
-      if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>,
-                                     &launch_pair_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>, stream))
+      if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true, false, ST>,
+                                     &launch_pair_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true, false, ST>, stream))
         return held < 0 ? held : CODON_OK;
-      return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true>(&p, stream);
+      return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, true, false, ST>(&p, stream);
     }
   }
-  return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, false>(&p, stream);
+  return launch_single_f32<KS, CIN, COUT, PSEG, FUSE, GATE, NW, false, false, ST>(&p, stream);
 }
 
 template <int KS, int CIN, int COUT, int PSEG, bool CSPLIT = false>
@@ -723,6 +806,7 @@ static int launch_conv_p(const codon_conv_desc* d, const float* x, const float* 
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.gout = nullptr; p.go_img = p.go_base = 0;
+  p.st_pool = nullptr; p.st_part = nullptr; p.st_choff = 0;
   if constexpr (CSPLIT)            // a small launch (see conv_chain1x1_fwd_f32): 2 x 32 tiles, couts split over the waves
     return launch_or_hold_csplit_f32<KS, CIN, COUT, false, 4>(p, stream);
   return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, false, 4>(p, PSEG == 1 && solo, stream);
@@ -776,6 +860,7 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
   p.gout = gated_out ? (float*)gated_out->data : nullptr;
   p.go_img = gated_out ? gated_out->ctotal * HW : 0; p.go_base = gated_out ? gated_out->coff * HW : 0;
   p.w2 = nullptr; p.y2 = nullptr; p.y2_img = p.y2_base = 0;
+  p.st_pool = nullptr; p.st_part = nullptr; p.st_choff = 0;
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
@@ -811,9 +896,11 @@ int conv2d_gated_fwd_f32(const codon_conv_desc* d, const float* pre, const codon
   }
 }
 
-// d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1
+// d: the 5x5 128 -> 128 conv (y nullable); out / res: 64-channel slices of the chained 1x1; st_pool / st_part non-null: the
+// epilogue also leaves the CAC statistics of the 64 output channels (ST kernels; any tiling gives the same bits)
 int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float* w, float* y, const float* w_chain,
-                          const codon_tensor* out, const codon_tensor* res, hipStream_t stream) {
+                          const codon_tensor* out, const codon_tensor* res, float* st_pool, float* st_part, int st_choff,
+                          hipStream_t stream) {
   CODON_REQUIRE(d->ksize == 5 && d->cin == 128 && d->cout == 128, CODON_ERR_UNSUPPORTED,
                 "conv_chain1x1_fwd: f32 kernel is conv5x5 128->128 + 1x1 128->64 (got k=%d %d->%d)", d->ksize, d->cin, d->cout);
   constexpr int NWC = 4;     // waves per workgroup (one 8-wave workgroup per CU on a 16x32 tile measured slower: DESIGN.md 3.1)
@@ -829,6 +916,9 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
   p.in2 = nullptr; p.ch = nullptr; p.sp = nullptr; p.in_img = p.in_base = 0;
   p.gout = nullptr; p.go_img = p.go_base = 0;
   p.w2 = w_chain; p.y2 = (float*)out->data; p.y2_img = out->ctotal * HW; p.y2_base = out->coff * HW;
+  p.st_pool = st_pool; p.st_part = st_part; p.st_choff = st_choff;
+  const bool st = st_part != nullptr;
+  CODON_REQUIRE(!st || (st_pool && !res), CODON_ERR_BAD_ARG, "conv_chain1x1_stats_fwd: statistics need both outputs and no residual");
   p.tiles_x = (d->width + 31) / 32;
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
@@ -845,7 +935,12 @@ int conv_chain1x1_fwd_f32(const codon_conv_desc* d, const float* x, const float*
     // 128 in each launch of a pair (the two streams of a block): 2 x 32 tiles, couts split over the waves
     p.tiles_y = (d->height + 1) / 2;
     p.nblk = (int)((long)p.tiles_x * p.tiles_y * d->batch);
+    if (st) return launch_or_hold_csplit_f32<5, 128, 128, true, NWC, true>(p, stream);
     return launch_or_hold_csplit_f32<5, 128, 128, true, NWC>(p, stream);
+  }
+  if (st) {
+    if (mode != GRID_8X32) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC, true>(p, small, stream);
+    return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC, true>(p, false, stream);
   }
   if (mode != GRID_8X32) return launch_or_hold_f32<5, 128, 128, 1, true, false, NWC>(p, small, stream);
   return launch_or_hold_f32<5, 128, 128, 2, true, false, NWC>(p, false, stream);

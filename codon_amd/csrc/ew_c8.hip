@@ -150,9 +150,11 @@ int stem_fwd_c8(int B, int H, int W, const float* x, const float* w, void* y, in
 // times) and accumulates V[r][dx] with the plane's 72 weights held in registers; the three column terms of an output
 // meet through two lane shuffles at the end.  Every load is an unconditional buffer instruction: off-image columns
 // carry an out-of-range offset, off-image rows a zero-length descriptor (wave-uniform select).
-template <class E, int R>
+// Y16: the output map is stored in the activations' 16-bit type (a model cast as a whole, test.py:52, returns 16 bits): the
+// fp32 sum rounded once -- the value an fp32 store followed by a conversion pass gives, without the pass.
+template <class E, int R, bool Y16 = false>
 __global__ __launch_bounds__(256) void head_c8_kernel(C8Slice x, const float* __restrict__ w,
-                                                      const float* __restrict__ res, float* __restrict__ y, int H, int W,
+                                                      const float* __restrict__ res, void* __restrict__ yv, int H, int W,
                                                       int nband, int nseg, long nwave, int nblk) {
   __shared__ float wsh[8 * 9 * 8];                      // [plane][tap][8 ch]
   for (int i = threadIdx.x; i < 576; i += 256) {
@@ -219,25 +221,31 @@ __global__ __launch_bounds__(256) void head_c8_kernel(C8Slice x, const float* __
     const int gy = gy0 + r;
     if (act && gy < H) {
       const long off = (long)b * HW + (long)gy * W + col;
-      y[off] = (left + V[r][1] + right) + res[off];
+      const float v = (left + V[r][1] + right) + res[off];
+      if constexpr (Y16) reinterpret_cast<unsigned short*>(yv)[off] = (unsigned short)(E::pack2(v, 0.f) & 0xffffu);
+      else reinterpret_cast<float*>(yv)[off] = v;
     }
   }
 }
 
 template <class E, int R>
-static int head_c8_launch(int B, int H, int W, C8Slice x, const float* w, const float* res, float* y, hipStream_t stream) {
+static int head_c8_launch(int B, int H, int W, C8Slice x, const float* w, const float* res, void* y, bool y16, hipStream_t stream) {
   const int nband = (H + R - 1) / R;
   const int nseg = (W + 61) / 62;
   const long nwave = (long)B * nband * nseg;
   const long blocks = (nwave + 3) / 4;
   CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "head_fwd: grid too large");
-  hipLaunchKernelGGL((head_c8_kernel<E, R>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W, nband, nseg,
-                     nwave, (int)blocks);
+  if (y16)
+    hipLaunchKernelGGL((head_c8_kernel<E, R, true>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W, nband,
+                       nseg, nwave, (int)blocks);
+  else
+    hipLaunchKernelGGL((head_c8_kernel<E, R, false>), dim3((unsigned)blocks), dim3(256), 0, stream, x, w, res, y, H, W, nband,
+                       nseg, nwave, (int)blocks);
   return check_launch("head_c8_kernel");
 }
 
-int head_fwd_c8(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
-                int dtype, hipStream_t stream) {
+int head_fwd_c8(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, void* y,
+                bool y16, int dtype, hipStream_t stream) {
   CODON_REQUIRE(c8_slice_ok(x_ctotal, x_coff, 64), CODON_ERR_BAD_ARG,
                 "head_fwd: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
   const long HW = (long)H * W;
@@ -245,8 +253,8 @@ int head_fwd_c8(int B, int H, int W, const void* x, int x_ctotal, int x_coff, co
   const C8Slice xs = c8_mk(x, x_ctotal, x_coff, HW);
   const bool big = (long)B * H * W >= (1L << 22);
   if (dtype == CODON_F16)
-    return big ? head_c8_launch<C8F16, 8>(B, H, W, xs, w, res, y, stream) : head_c8_launch<C8F16, 4>(B, H, W, xs, w, res, y, stream);
-  return big ? head_c8_launch<C8Bf16, 8>(B, H, W, xs, w, res, y, stream) : head_c8_launch<C8Bf16, 4>(B, H, W, xs, w, res, y, stream);
+    return big ? head_c8_launch<C8F16, 8>(B, H, W, xs, w, res, y, y16, stream) : head_c8_launch<C8F16, 4>(B, H, W, xs, w, res, y, y16, stream);
+  return big ? head_c8_launch<C8Bf16, 8>(B, H, W, xs, w, res, y, y16, stream) : head_c8_launch<C8Bf16, 4>(B, H, W, xs, w, res, y, y16, stream);
 }
 
 // ---- weight gradient of the 1->64 / 64->1 3x3 convs ------------------------------------------------------------------

@@ -266,7 +266,7 @@ static int stem_launch(int B, int H, int W, const float* x, const float* w, T* y
 
 // ew_c8.hip: the same stencils over channel-blocked 16-bit tensors
 int stem_fwd_c8(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
-int head_fwd_c8(int, int, int, const void*, int, int, const float*, const float*, float*, int, hipStream_t);
+int head_fwd_c8(int, int, int, const void*, int, int, const float*, const float*, void*, bool, int, hipStream_t);
 size_t conv1ch_wgrad_c8_workspace_bytes(int, int, int);
 int conv1ch_wgrad_c8(int, int, int, const void*, int, int, const float*, float*, int, float*, size_t, int, hipStream_t);
 
@@ -323,10 +323,11 @@ static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff
              : head_launch_v<1, 4, T, 8>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
 }
 
-int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, float* y,
-             int dtype, hipStream_t stream) {
-  if (dtype != CODON_F32) return head_fwd_c8(B, H, W, x, x_ctotal, x_coff, w, res, y, dtype, stream);
-  return head_launch<float>(B, H, W, (const float*)x, x_ctotal, x_coff, w, res, y, stream);
+// y16 (16-bit activations only): y is stored in the activations' type instead of fp32
+int head_fwd(int B, int H, int W, const void* x, int x_ctotal, int x_coff, const float* w, const float* res, void* y,
+             bool y16, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32) return head_fwd_c8(B, H, W, x, x_ctotal, x_coff, w, res, y, y16, dtype, stream);
+  return head_launch<float>(B, H, W, (const float*)x, x_ctotal, x_coff, w, res, (float*)y, stream);
 }
 
 // ---- weight gradient of the 1->64 / 64->1 3x3 convs ----------------------------------------------

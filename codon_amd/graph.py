@@ -18,17 +18,22 @@ class GraphedCODON:
             # checksum the captured launch compares with; none of that may happen for the first time under capture
             raise ValueError("GraphedCODON: warmup must be >= 1")
         self.model = model.eval()
-        self.x = example_x.detach().clone().float().contiguous()
-        self.y = example_y.detach().clone().float().contiguous()
+        # 16-bit images for a model whose activations have that type (the reference script's model.cuda().half() on .half()
+        # inputs, test.py:52,122-123) stay 16-bit: the captured forward converts them in its own first launch and its head
+        # stores the 16-bit output -- no conversion launches outside the graph
+        self.io_dtype = example_x.dtype if (example_x.dtype == example_y.dtype and example_x.dtype != torch.float32 and
+                                            example_x.dtype == self.model._act_dtype()) else torch.float32
+        self.x = example_x.detach().clone().to(self.io_dtype).contiguous()
+        self.y = example_y.detach().clone().to(self.io_dtype).contiguous()
         side = torch.cuda.Stream(device=self.x.device)
         side.wait_stream(torch.cuda.current_stream(self.x.device))
         with torch.no_grad(), torch.cuda.stream(side):
             for _ in range(warmup):                      # packs the weights, warms the allocator
-                self.model._forward_impl(self.x, self.y, None)
+                self.model._forward_impl(self.x, self.y, None, out_dtype=self.io_dtype)
         torch.cuda.current_stream(self.x.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = self.model._forward_impl(self.x, self.y, None)
+            self.out = self.model._forward_impl(self.x, self.y, None, out_dtype=self.io_dtype)
         # the captured launches carry raw addresses of the packed weight images (ordinary allocator pool) and of the
         # small fp32 parameters: keep the former alive for the graph's lifetime and remember which weight values
         # they were packed from, so a replay after a weight update is refused instead of silently stale

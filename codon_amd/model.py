@@ -47,8 +47,29 @@ PAIR_MAX16 = int(_os.environ.get("CODON_PAIR_MAX16", "4096"))
 PAIR_MAX32 = int(_os.environ.get("CODON_PAIR_MAX32", "383"))
 # the whole gate of a block -- pool finish, MLP, spatial conv -- in one launch (codon_cac_tail_fwd); 0 = three / four launches (A/B)
 CAC_TAIL = _os.environ.get("CODON_CAC_TAIL", "1") != "0"
+# fp32, images of at most 32 768 pixels: the CAC statistics out of the chained conv's epilogue; 0 = the statistics pass (A/B)
+FUSED_STATS_F32 = _os.environ.get("CODON_FUSED_STATS_F32", "1") != "0"
 CAC_TAIL_MAX_PIXELS = 1 << 21
 _HALF_STREAMS: Dict[tuple, tuple] = {}
+_TAIL_COUNTERS: Dict[tuple, torch.Tensor] = {}
+
+
+def _tail_counters(dev, B: int) -> torch.Tensor:
+    """The arrival counters of codon_cac_tail_fwd: zero on entry, left at zero by every launch -- so ONE zeroed buffer per
+    (device, calling stream, host thread) serves every forward instead of a torch.zeros (an ATen fill launch, 5 us of a 2 ms
+    one-image forward) per call.  Private to the (stream, thread) like the side streams above: launches of independent
+    callers never count in each other's words; a larger batch replaces the buffer."""
+    import threading
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (i, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
+    t = _TAIL_COUNTERS.get(key)
+    if t is None or t.numel() < B:
+        if torch.cuda.is_current_stream_capturing():
+            # never cache an allocation made inside a hipGraph capture (it belongs to the graph's pool)
+            return torch.zeros((B,), dtype=torch.int32, device=dev)
+        _prune_dead_threads(_TAIL_COUNTERS, 2)
+        t = _TAIL_COUNTERS[key] = torch.zeros((max(B, 64),), dtype=torch.int32, device=dev)
+    return t
 
 
 def _half_chip_streams(dev, main_stream):
@@ -537,8 +558,10 @@ class _CODONBase(nn.Module):
             else:
                 from .autograd import codon_apply  # training path (custom backward)
                 return codon_apply(self, x, y)
-        out = self._forward_impl(x.float().contiguous(), y.float().contiguous(), None)
-        return out if x.dtype == torch.float32 else out.to(x.dtype)
+        # 16-bit inputs (the reference script's `.half()` images, test.py:122-123) go in as they are: _forward_impl converts them
+        # in the launch that converts the model's small parameters (codon_cast_multi) -- no ATen cast per image
+        # ... and the head stores the output map in the inputs' 16-bit type itself (codon_head_fwd_y16)
+        return self._forward_impl(x.contiguous(), y.contiguous(), None, out_dtype=x.dtype)
 
     def _empty_batch(self, x, y):
         """An empty batch (a rank whose shard of a small global batch holds no image, dist.shard_batch): every op of the
@@ -553,9 +576,11 @@ class _CODONBase(nn.Module):
                 out = out + sum((t.sum() * 0).to(out.dtype) for t in live)
         return out
 
-    def _forward_impl(self, x, y, save: Optional[dict]):
+    def _forward_impl(self, x, y, save: Optional[dict], out_dtype: Optional[torch.dtype] = None):
         """Kernel schedule of CODONNet.forward.  With `save` (a dict) every activation the
-        backward needs is kept in fresh buffers; without it buffers are reused across blocks."""
+        backward needs is kept in fresh buffers; without it buffers are reused across blocks.
+        x, y: fp32, or 16-bit (converted here, in the launch that converts a 16-bit model's small parameters);
+        out_dtype: dtype of the returned map (default fp32; a 16-bit type only with 16-bit activations of that type)."""
         B, _, H, W = x.shape
         dev = x.device
         self.check_supported()
@@ -577,14 +602,17 @@ class _CODONBase(nn.Module):
             ops.conv_chain1x1(xs, P(name5), P(name1, chain_mode), ys, mid=mid if keep else None, residual=residual,
                               f16x3=split5, stats=stats)
 
-        # 16-bit tensors: the CAC statistics of a block come out of the two conv5x5 + 1x1 epilogues (no pass over Fcat)
-        fused_stats = ops.is_c8(adt)
+        # 16-bit tensors: the CAC statistics of a block come out of the two conv5x5 + 1x1 epilogues (no pass over Fcat).
+        # fp32 (round 6): the same for images of at most 32 768 pixels -- chosen by H x W ONLY, and the per-row-strip partials
+        # are tiling-invariant, so an image's bits do not depend on the batch it arrives in; larger fp32 images keep the
+        # statistics pass (0.87 ms of a 988 ms forward at 32 x 480 x 640, against 5 x 22 us of 2.2 ms at 1 x 128 x 128)
+        fused_stats = ops.is_c8(adt) or (FUSED_STATS_F32 and CAC_TAIL and adt == torch.float32 and not split5 and H * W <= 32768)
 
         # inference, exact fp32: the gate-apply `out*ad_CAC + inputs` (:89-91,117-118) is formed inside the staging of
         # the convs that consume it (codon_conv2d_gated_fwd) instead of a 15 GB HBM pass per block
         # 16-bit: with the emitting conv5x5 (GATED_EMIT) the training forward takes the same route -- the emitted tensor IS
         # the block input the backward needs, bit-identical to cac_apply's output, and the 7.5 GB apply pass is gone there too
-        emit16 = GATED_EMIT and not split5 and ((fused_stats and GATED_16BIT) or (adt == torch.float32 and not keep))
+        emit16 = GATED_EMIT and not split5 and ((ops.is_c8(adt) and GATED_16BIT) or (adt == torch.float32 and not keep))
         gated = not split5 and (((not keep) and (adt == torch.float32 or GATED_16BIT)) or (keep and emit16))
 
         emit16 = emit16 and gated
@@ -603,11 +631,13 @@ class _CODONBase(nn.Module):
         # the small parameters the kernels take in fp32 (stems, head, the 25 gate tensors): themselves, or -- a model cast to
         # 16 bits as a whole, test.py:52 -- one flat fp32 copy made by ONE launch per forward from the live parameters
         gmods = [(getattr(self, f"attention_c{i}"), getattr(self, f"attention_s{i}")) for i in range(5)]
-        small = ops.params_f32([self.input.weight, self.input_c.weight, self.output.weight] +
+        # ... and 16-bit input images with them (first in the list: the kernel finds an element's tensor by a linear search)
+        small = ops.params_f32([x, y, self.input.weight, self.input_c.weight, self.output.weight] +
                                [t for ac, asp in gmods for t in (ac.mlp[1].weight, ac.mlp[1].bias, ac.mlp[3].weight,
                                                                  ac.mlp[3].bias, asp.spatial.conv.weight)])
-        w_in, w_in_c, w_out = small[:3]
-        gparams = [small[3 + 5 * i: 8 + 5 * i] for i in range(5)]      # (w1, b1, w2, b2, ws) of block i
+        x, y = small[:2]
+        w_in, w_in_c, w_out = small[2:5]
+        gparams = [small[5 + 5 * i: 10 + 5 * i] for i in range(5)]      # (w1, b1, w2, b2, ws) of block i
 
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
         in2 = new(128)
@@ -665,7 +695,7 @@ class _CODONBase(nn.Module):
                 main_s.wait_stream(halves[0])
                 main_s.wait_stream(halves[1])
 
-        nt = ops.cac_fused_tiles(H, W) if fused_stats else ops.cac_stats_tiles(H, W)
+        nt = ops.cac_fused_parts(H, W, adt) if fused_stats else ops.cac_stats_tiles(H, W)
         fz = dict(dtype=torch.float32, device=dev)
         # fp32: the one-launch gate folds the tiles before it finishes the pools -- the serial order of cac_gate_kernel while every
         # fold holds one tile (nt <= 16), and the ONLY sensible form for the many small tiles of a small image (H W <= 32768:
@@ -673,12 +703,13 @@ class _CODONBase(nn.Module):
         # 16-bit: bit-identical to the separate launches at any size, and FASTER only while the grid is small (12 vs 25 us for
         # one 370 x 463 image; 210 vs 147 us at 32 x 480 x 640, where the combine inside the spatial tiles re-reads four maps'
         # halos) -- so it is chosen by size there; fp32: by H x W only, so that an image's bits never depend on its batch
-        tail = CAC_TAIL and (B * H * W <= CAC_TAIL_MAX_PIXELS if fused_stats else (nt <= L.CAC_FOLDS or H * W <= 32768))
+        tail = CAC_TAIL and ((B * H * W <= CAC_TAIL_MAX_PIXELS or adt == torch.float32) if fused_stats
+                             else (nt <= L.CAC_FOLDS or H * W <= 32768))
         if fused_stats:
             pool_c, pool_d = torch.empty((B, 2, H, W), **fz), torch.empty((B, 2, H, W), **fz)
         if fused_stats or tail:
             folded = torch.empty((B, L.CAC_FOLDS, 128, 2), **fz)
-        counters = torch.zeros((B,), dtype=torch.int32, device=dev) if tail else None    # arrival counters: left at zero by every launch
+        counters = _tail_counters(dev, B) if tail else None    # arrival counters: zero on entry, left at zero by every launch
         cur = in2                       # (B,128): [depth | colour] block input
         oc = prev_gate = prev_pre2 = None
         stage = r2 = stage_c = r2_c = pre2 = None
@@ -788,8 +819,14 @@ class _CODONBase(nn.Module):
         # tail                                                                       :129-132
         t = new(64) if keep else t64
         conv(Slice(f), "conv11", Slice(t), 3, relu=True)
-        outp = torch.empty_like(x)
-        ops.head(Slice(t), w_out, x, outp)
+        if out_dtype is not None and out_dtype != torch.float32 and out_dtype == adt:
+            outp = torch.empty(x.shape, dtype=out_dtype, device=dev)     # the head rounds once, in its store
+            ops.head(Slice(t), w_out, x, outp)
+        else:
+            outp = torch.empty_like(x)
+            ops.head(Slice(t), w_out, x, outp)
+            if out_dtype is not None and out_dtype != torch.float32:
+                outp = outp.to(out_dtype)     # e.g. bf16 inputs to an fp32 model: not the reference's use, one ATen cast
         if keep:
             save["f_last"], save["t11"] = f, t
         return outp

@@ -244,8 +244,9 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
                   residual: Optional[Slice] = None, f16x3: bool = False, stats=None):
     """out = conv1x1(relu(conv5x5(x))) [+ residual] in one launch (the 1x1 runs from the 5x5's accumulators);
     mid, when given, also receives relu(conv5x5(x)) (training saves it).  stats = (pool (B,2,H,W), partials
-    (B, cac_fused_tiles, 128, 2), choff in {0, 64}): 16-bit tensors only -- the launch also leaves the CAC statistics of
-    its 64 output channels (csrc/conv_c8.hip; finished by cac_fused_finish + cac_gate_folded)."""
+    (B, cac_fused_parts(H, W, dtype), 128, 2), choff in {0, 64}): the launch also leaves the CAC statistics of its 64
+    output channels (16-bit: csrc/conv_c8.hip, per-tile partials; fp32: per-row-strip partials, tiling-invariant; finished
+    by cac_tail, or cac_fused_finish + cac_gate_folded)."""
     lib = L.load()
     dev = _dev(x.buf, w_packed, w_chain, out.buf, mid.buf if mid else None, residual.buf if residual else None,
                stats[0] if stats else None, stats[1] if stats else None)
@@ -265,7 +266,7 @@ def conv_chain1x1(x: Slice, w_packed: torch.Tensor, w_chain: torch.Tensor, out: 
         if stats is not None:
             pool, partials, choff = stats
             assert pool.dtype == torch.float32 and tuple(pool.shape) == (B, 2, H, W)
-            assert partials.dtype == torch.float32 and tuple(partials.shape) == (B, cac_fused_tiles(H, W), 128, 2)
+            assert partials.dtype == torch.float32 and tuple(partials.shape) == (B, cac_fused_parts(H, W, x.buf.dtype), 128, 2)
             L.check(lib.codon_conv_chain1x1_stats_fwd(C.byref(d), _ptr(x.buf), _ptr(w_packed),
                                                       _ptr(mid.buf if mid else None), _ptr(w_chain), C.byref(ot),
                                                       C.byref(rt) if rt is not None else None, _ptr(pool), _ptr(partials),
@@ -433,7 +434,14 @@ def head(x: Slice, w: torch.Tensor, residual: torch.Tensor, y: torch.Tensor):
     lib = L.load()
     dev = _dev(x.buf, w, residual, y)
     B, H, W = _bhw(x.buf)
-    assert x.c == 64 and w.dtype == torch.float32 and residual.dtype == torch.float32 and y.dtype == torch.float32
+    assert x.c == 64 and w.dtype == torch.float32 and residual.dtype == torch.float32
+    if y.dtype != torch.float32:
+        # 16-bit output map of a 16-bit model (codon_head_fwd_y16): the fp32 result rounded once in the store
+        assert is_c8(x.buf.dtype) and y.dtype == x.buf.dtype and y.is_contiguous()
+        with _on(dev):
+            L.check(lib.codon_head_fwd_y16(B, H, W, _ptr(x.buf), x.ctotal, x.coff, _ptr(w), _ptr(residual), _ptr(y),
+                                           _dt(x.buf), _stream(dev)), "head_fwd_y16")
+        return
     with _on(dev):
         L.check(lib.codon_head_fwd(B, H, W, _ptr(x.buf), x.ctotal, x.coff, _ptr(w), _ptr(residual), _ptr(y),
                                    _dt(x.buf), _stream(dev)), "head_fwd")
@@ -447,14 +455,21 @@ def cac_fused_tiles(H: int, W: int) -> int:
     return L.load().codon_cac_fused_tiles(H, W)
 
 
+def cac_fused_parts(H: int, W: int, dtype) -> int:
+    """Rows per image of the fused-statistics partials for activations of `dtype` (codon_cac_fused_parts)."""
+    code = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[dtype]
+    return L.load().codon_cac_fused_parts(H, W, code)
+
+
 def params_f32(tensors):
     """The given small parameter tensors as fp32: themselves when they already are, else views of ONE flat fp32 buffer
     filled by one launch (codon_cast_multi) -- a 16-bit model's stems, head and gate tensors, read live on every call."""
     tensors = list(tensors)
-    if all(t.dtype == torch.float32 for t in tensors):
-        return [t.detach() for t in tensors]
+    out = [t.detach() if t.dtype == torch.float32 else None for t in tensors]
+    todo = [i for i, o in enumerate(out) if o is None]
+    if not todo:
+        return out
     lib = L.load()
-    out, todo = [None] * len(tensors), list(range(len(tensors)))
     while todo:
         idx, todo = todo[:L.CAST_MAX], todo[L.CAST_MAX:]
         dev = _dev(*[tensors[i] for i in idx])

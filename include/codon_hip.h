@@ -126,8 +126,8 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
                             const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
                             codon_stream_t stream);
 
-/* 16-bit tensors only: codon_conv_chain1x1_fwd that ALSO produces the CAC statistics of its 64 output channels from the
- * epilogue (the values as stored, i.e. rounded to 16 bits), instead of a separate pass over the tensor
+/* codon_conv_chain1x1_fwd that ALSO produces the CAC statistics of its 64 output channels from the
+ * epilogue (the values as stored, i.e. 16-bit tensors: rounded to 16 bits), instead of a separate pass over the tensor
  * (codon_cac_stats_fwd; F.avg_pool2d / F.max_pool2d / ChannelPool, /root/reference/CODON_X4/CAC_module.py:43,47,81):
  *   stats_pool     (B,2,H,W) fp32 : per pixel { max, SUM } over THIS stream's 64 channels
  *   stats_partials (B, codon_cac_fused_tiles(H,W), 128, 2) fp32 : per conv tile, per channel { sum, max } written at
@@ -142,6 +142,13 @@ int codon_conv_chain1x1_stats_fwd(const codon_conv_desc* d, const void* x, const
                                   const void* w_chain, const codon_tensor* out, const codon_tensor* residual,
                                   float* stats_pool, float* stats_partials, int32_t stats_choff, codon_stream_t stream);
 int32_t codon_cac_fused_tiles(int32_t height, int32_t width);
+/* Rows per image of stats_partials for tensors of `dtype`: 16-bit = codon_cac_fused_tiles; fp32 (round 6) = one row per STRIP
+ * of 32 pixels of one image row, height * ceil(width / 32).  fp32 strips are summed by one fixed in-wave tree and folded in
+ * index order by codon_cac_tail_fwd, so the statistics -- and with them the gates and the image -- do not depend on which
+ * tiling (8 x 32, 4 x 32, 2 x 32 cout-split: codon_conv_tiling_f32) the launch took, i.e. not on the batch an image arrives in.
+ * fp32: no residual; the model uses it for images of at most 32 768 pixels (by height x width only), where the separate
+ * statistics pass cost 22 us of a 2.2 ms forward (BASELINE configs[0]). */
+int32_t codon_cac_fused_parts(int32_t height, int32_t width, int32_t dtype);
 int codon_cac_fused_finish(int32_t batch, int32_t height, int32_t width, const float* partials, const float* pool_c,
                            const float* pool_d, float* folded, float* pooled, codon_stream_t stream);
 int codon_cac_gate_folded_fwd(int32_t batch, int32_t height, int32_t width, const float* folded, const float* w1,
@@ -253,6 +260,13 @@ int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
 int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal,
                    int32_t x_coff, const float* w_oihw, const float* residual, float* y,
                    int32_t dtype, codon_stream_t stream);
+/* head with the output map stored in the activations' 16-bit type (dtype = CODON_BF16 / CODON_F16 only): what a module
+ * cast as a whole returns -- `model.cuda().half()`, /root/reference/CODON_X4/test.py:52,125.  The fp32 sum conv + residual
+ * rounded once: the bits of codon_head_fwd followed by a conversion pass, without the pass (one launch of ~40 at one image
+ * per call).  residual stays fp32 (B,1,H,W). */
+int codon_head_fwd_y16(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal,
+                       int32_t x_coff, const float* w_oihw, const float* residual, void* y16,
+                       int32_t dtype, codon_stream_t stream);
 
 /* ---- CAC gate (HBM-bound) -----------------------------------------------------------------
  * Fcat = cat(out_c, out) is never materialised: pre_c (colour, channels 0..63 of Fcat) and pre

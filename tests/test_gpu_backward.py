@@ -521,6 +521,8 @@ def test_packed_weight_verification_catches_data_writes(monkeypatch):
             warnings.simplefilter("error")       # and a clean model resets silently
             m.load_state_dict(m.state_dict())
             m.invalidate_packed()
+        m(x, x)                                  # packed images of the current weights exist again
+        m.check_packed()
         # the debug switch: same-call detection
         m.conv3.weight.data.mul_(0.5)
         monkeypatch.setattr(M, "VERIFY_PACKED", True)

@@ -1152,3 +1152,94 @@ def test_fp32_grid_modes_are_bit_identical():
             one = run(x[i:i + 1].contiguous(), r[i:i + 1].contiguous(), ch[i:i + 1].contiguous(), sp[i:i + 1].contiguous())
             for a, b_ in zip(full, one):
                 assert torch.equal(a[i:i + 1], b_), (H, i)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128), (1, 37, 70), (1, 64, 96), (2, 5, 3), (1, 1, 1), (1, 100, 200)])
+def test_fp32_fused_statistics_against_torch_and_in_every_tiling(shape):
+    """Round 6: the fp32 chained conv's statistics epilogue (codon_conv_chain1x1_stats_fwd on fp32 tensors,
+    csrc/conv_mfma_f32.hip ST kernels).  (a) against torch on the stored tensor: per-pixel max over the 64 channels and the
+    per-strip channel maxima bit for bit, sums to fp32 summation order (F.avg_pool2d / F.max_pool2d / ChannelPool,
+    /root/reference/CODON_X4/CAC_module.py:43,47,81); the conv output identical with and without the statistics.
+    (b) TILING INVARIANCE -- the reason the partials are per row strip: the image alone (2 x 32 cout-split, 4 x 32 one per CU),
+    as a pair launch, and repeated in a batch large enough for 4 x 32 two-per-CU and 8 x 32 tiles gives the SAME BITS in
+    pool and partials, so the gates of an image do not depend on the batch it arrives in."""
+    import ctypes as C
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    fz = dict(dtype=torch.float32, device=dev)
+    x = torch.relu(_rand((B, 128, H, W), 1)).to(dev)
+    w5 = _rand((128, 128, 5, 5), 11, (2.0 / (25 * 128)) ** 0.5).to(dev)
+    wc = _rand((64, 128, 1, 1), 21, 0.15).to(dev)
+    wp, wcp = ops.packed_weight(w5, L.PACK_FWD, torch.float32), ops.packed_weight(wc, L.PACK_CHAIN1X1, torch.float32)
+    nt = ops.cac_fused_parts(H, W, torch.float32)
+    assert nt == H * ((W + 31) // 32)
+
+    def run(xs, paired=False, choff=64):
+        b = xs.shape[0]
+        out = torch.full((b, 128, H, W), float("nan"), **fz)
+        pool = torch.full((b, 2, H, W), float("nan"), **fz)
+        part = torch.full((b, nt, 128, 2), float("nan"), **fz)
+        with ops.conv_pair(dev, paired):
+            ops.conv_chain1x1(Slice(xs), wp, wcp, Slice(out, 0, 64), stats=(pool, part, choff))
+            if paired:
+                ops.conv_chain1x1(Slice(xs), wp, wcp, Slice(out, 64, 64), stats=(pool.clone(), part, 64 - choff))
+        return out, pool, part
+
+    out, pool, part = run(x)
+    ref = torch.zeros((B, 64, H, W), **fz)
+    ops.conv_chain1x1(Slice(x), wp, wcp, Slice(ref))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :64], ref) and not torch.isnan(pool).any()
+    assert not torch.isnan(part[:, :, 64:]).any() and torch.isnan(part[:, :, :64]).all()     # only its own 64 channels
+    assert torch.equal(pool[:, 0], ref.amax(1))
+    assert rel_rmse(pool[:, 1].cpu(), ref.double().sum(1).float().cpu()) < 1e-6
+    tx = (W + 31) // 32
+    padded = torch.full((B, 64, H, tx * 32), float("-inf"), **fz)
+    padded[..., :W] = ref
+    strips = padded.view(B, 64, H, tx, 32)
+    want_max = strips.amax(4).permute(0, 2, 3, 1).reshape(B, nt, 64)
+    want_sum = torch.where(torch.isinf(strips), torch.zeros_like(strips), strips).double().sum(4).permute(0, 2, 3, 1).reshape(B, nt, 64)
+    assert torch.equal(part[:, :, 64:, 1], want_max)
+    assert float((part[:, :, 64:, 0].double() - want_sum).abs().max()) <= 2e-6 * (float(want_sum.abs().max()) + 1e-30)
+    # (b) the same image in other launch shapes
+    _, pool_p, part_p = run(x, paired=True)
+    assert torch.equal(pool_p, pool) and torch.equal(part_p[:, :, 64:], part[:, :, 64:])
+    tiling = lambda b: L.load().codon_conv_tiling_f32(C.byref(L.ConvDesc(b, H, W, 128, 128, 5, 128, 0, 128, 0, 0, 0, 0, L.F32)), 1, 0)
+    seen = {tiling(B)}
+    for rep in (3, 8, 40, 200):
+        if B * rep * H * W > 40 * 128 * 128:
+            break
+        xs = x.repeat(rep, 1, 1, 1)
+        seen.add(tiling(B * rep))
+        o2, pool2, part2 = run(xs)
+        for k in (0, rep - 1):
+            sl = slice(k * B, (k + 1) * B)
+            assert torch.equal(o2[sl, :64], ref) and torch.equal(pool2[sl], pool), (rep, k)
+            assert torch.equal(part2[sl][:, :, 64:], part[:, :, 64:]), (rep, k)
+    if H * W >= 64 * 96:
+        assert len(seen) >= 3, seen          # the premise: the sizes above really took different tilings
+
+
+def test_fp32_small_image_bits_do_not_depend_on_the_batch():
+    """The fp32 forward of images of at most 32 768 pixels takes its CAC statistics from the conv epilogue (round 6).  One
+    128 x 128 image (BASELINE configs[0]) alone, inside a batch of 5 and inside a batch of 32 -- cout-split pairs, 4 x 32 and
+    8 x 32 tiles -- comes out with identical bits, and within 1e-4 of the oracle."""
+    from codon_amd import CODONNet
+    from oracle import codon_oracle as orc
+    dev = _dev()
+    sd = orc.he_state("x4", seed=61)
+    m = CODONNet()
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    g = np.random.default_rng(8)
+    x = torch.from_numpy(g.random((32, 1, 128, 128), dtype=np.float32)).to(dev)
+    y = torch.from_numpy(g.random((32, 1, 128, 128), dtype=np.float32)).to(dev)
+    with torch.no_grad():
+        o32 = m(x, y)
+        o5 = m(x[3:8].contiguous(), y[3:8].contiguous())
+        o1 = m(x[5:6].contiguous(), y[5:6].contiguous())
+        ref = orc.forward(sd, x[5:6].cpu(), y[5:6].cpu())
+    assert torch.equal(o32[5:6], o1) and torch.equal(o5[2:3], o1)
+    assert rmse(o1.cpu(), ref) <= 1e-4 and rel_rmse(o1.cpu(), ref) <= 2e-5
