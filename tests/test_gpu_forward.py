@@ -86,20 +86,25 @@ def test_forward_at_the_reference_scripts_image_sizes(shape):
     with torch.no_grad():
         o = m(x.cuda(), y.cuda())
     assert rmse(o.cpu(), ref) <= RMSE_TOL and rel_rmse(o.cpu(), ref) <= 2e-5
-    # the script's precision at these sizes: no further from the fp32 oracle than 1.25 x the ORACLE RUN IN fp16 on the CPU
-    # is -- the oracle in fp16 reproduces the reference module's own .half() run to 1e-6 (tests/test_oracle.py::
-    # test_oracle_in_fp16_reproduces_the_reference_modules_half_run; with these random inputs it sits at 2.7e-3, with the
-    # fixtures' inputs at 1.0-1.4e-3).  The same ratio against RECORDED reference outputs, one of them at 370 x 463:
-    # test_forward_half_vs_reference_module_run_in_half.
-    with torch.no_grad():
-        ref16 = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half()).float()
-    ref_err = rel_rmse(ref16, ref)
+    # the script's precision at these sizes, against the reference module's OWN .half() run on these very inputs
+    # (tests/golden/fp16ref_script_sizes.npz, tools/make_golden_r2.py: every 7th pixel of its fp16 and fp64 outputs, recorded
+    # in the build container -- the GPU box's CPU runs fp16 convs far too slowly to recompute it there): no further from fp64
+    # than 1.25 x the reference.  (The same ratio on a full recorded image: test_forward_half_vs_reference_module_run_in_half.)
+    import os
+    from tests.util import GOLD
+    z = np.load(os.path.join(GOLD, "fp16ref_script_sizes.npz"))
+    tag, sub = f"{H}x{W}", int(z["sub"])
+    assert float(z[tag + ".x00"]) == float(x[0, 0, 0, 0]) and float(z[tag + ".y_last"]) == float(y[0, 0, -1, -1])
+    assert rel_rmse(ref.reshape(-1)[::sub], z[tag + ".out_fp64_sub"]) <= 2e-5          # same weights, same inputs
+    ref_err = rel_rmse(z[tag + ".out_fp16_sub"].astype(np.float32), z[tag + ".out_fp64_sub"])
     mh = _model("x4", sd).half()
     with torch.no_grad():
         oh = mh(x.cuda().half(), y.cuda().half())
-    our_err = rel_rmse(oh.float().cpu(), ref)
-    print(f"{shape}: HIP fp16 vs fp32 oracle {our_err:.3e}, oracle-in-fp16 {ref_err:.3e}, ratio {our_err / ref_err:.3f}")
-    assert 5e-4 < ref_err < 5e-3 and our_err <= 1.25 * ref_err, (our_err, ref_err)
+    assert oh.dtype == torch.float16
+    our_err = rel_rmse(oh.float().cpu().reshape(-1)[::sub], z[tag + ".out_fp64_sub"])
+    print(f"{shape}: HIP fp16 vs fp64 {our_err:.3e}, reference .half() {ref_err:.3e}, ratio {our_err / ref_err:.3f}")
+    assert abs(ref_err - float(z[tag + ".ref_err_full"])) <= 0.05 * ref_err          # the subsample represents the image
+    assert our_err <= 1.25 * ref_err, (our_err, ref_err)
 
 
 def test_batch_independence_and_determinism():
@@ -200,15 +205,14 @@ def test_forward_half_like_reference_script(name):
     with torch.no_grad():
         o = m(x.cuda().half(), y.cuda().half())
     assert o.dtype == torch.float16 and o.shape == x.shape
-    # fp16 has 11 significand bits: ~8x tighter than bf16.  Bound: 1.25 x the error of the oracle run in fp16 on the CPU
-    # (= the reference module's .half() run to 1e-6, tests/test_oracle.py) on the same case; the cases that have a
-    # RECORDED reference fp16 output are held to it in test_forward_half_vs_reference_module_run_in_half.  One pixel
-    # (kat0_x4_1x1x1: 0.000516, fp16 spacing 4.8e-7 = 9e-4 relative) is one noise sample per side, not a statistic:
-    # there the bound is the reference's own error plus two fp16 spacings.
-    with torch.no_grad():
-        ref16 = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half()).float()
-    ref_err, our_err = rel_rmse(ref16, z["out_fp64"]), rel_rmse(o.float().cpu(), z["out_fp64"])
-    print(f"{name}: HIP fp16 vs fp64 {our_err:.3e}, oracle-in-fp16 {ref_err:.3e}")
+    # fp16 has 11 significand bits: ~8x tighter than bf16.  Bound: 1.25 x the error of the reference module's own .half()
+    # run on the same case (tests/golden/fp16ref_*.npz).  One pixel (kat0_x4_1x1x1: 0.000516, fp16 spacing 4.8e-7 = 9e-4
+    # relative) is one noise sample per side, not a statistic: there the bound is the reference's error plus two spacings.
+    zr, _, _, _, _ = load_case("fp16ref_" + name.replace("_taps", ""))
+    assert np.array_equal(zr["out_fp64"], z["out_fp64"])
+    ref_err = rel_rmse(zr["out_fp16"].astype(np.float32), z["out_fp64"])
+    our_err = rel_rmse(o.float().cpu(), z["out_fp64"])
+    print(f"{name}: HIP fp16 vs fp64 {our_err:.3e}, reference .half() {ref_err:.3e}")
     if x.numel() == 1:
         assert our_err <= ref_err + 2 * 2.0 ** -11, (our_err, ref_err)
     else:
@@ -233,7 +237,7 @@ def test_forward_half_vs_reference_module_run_in_half(name):
     OWN fp16 error on the same case and (b) within 2.5 x that of the reference's fp16 output (two independent fp16
     roundings of the same quantity differ by ~sqrt(2) x one)."""
     z, variant, sd, x, y = load_case(name)
-    assert len(FP16_REF_CASES) == 4
+    assert len(FP16_REF_CASES) == 6
     m = _model(variant, sd).half()
     with torch.no_grad():
         o = m(x.cuda().half(), y.cuda().half())
@@ -243,7 +247,10 @@ def test_forward_half_vs_reference_module_run_in_half(name):
     ref_err = rel_rmse(ref16, z["out_fp64"])
     our_err = rel_rmse(o, z["out_fp64"])
     print(f"{name}: HIP fp16 vs fp64 {our_err:.3e}, reference fp16 vs fp64 {ref_err:.3e}, ratio {our_err / ref_err:.3f}")
-    assert 5e-4 < ref_err < 3e-3
+    assert 5e-4 < ref_err < 4e-3
+    if x.numel() == 1:          # one pixel: one noise sample per side, not a statistic (see test_forward_half_like_reference_script)
+        assert our_err <= ref_err + 2 * 2.0 ** -11, (our_err, ref_err)
+        return
     assert our_err <= 1.25 * ref_err, (our_err, ref_err)
     assert rel_rmse(o, ref16) <= 2.5 * ref_err
     # fp32 master weights + fp16 compute is at least as close

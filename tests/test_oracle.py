@@ -111,7 +111,7 @@ def test_oracle_in_fp16_reproduces_the_reference_modules_half_run(name):
     /root/reference/CODON_X4/test.py:52,122-125 runs.  The oracle is the same ATen ops in the same order, so run in
     float16 it reproduces that output, and the fixture's fp32 / fp64 outputs pin it as the others do."""
     z, variant, sd, x, y = load_case(name)
-    assert len(FP16_REF_CASES) == 4
+    assert len(FP16_REF_CASES) == 6
     with torch.no_grad():
         o32 = orc.forward(sd, x, y)
         oh = orc.forward({k: t.half() for k, t in sd.items()}, x.half(), y.half())
@@ -119,7 +119,7 @@ def test_oracle_in_fp16_reproduces_the_reference_modules_half_run(name):
     assert rmse(o32, z["out"]) <= RMSE_TOL and rmse(o32, z["out_fp64"]) <= 2e-5
     assert rel_rmse(oh.float(), z["out_fp16"].astype(np.float32)) <= 1e-6
     ref_err = rel_rmse(z["out_fp16"].astype(np.float32), z["out_fp64"])
-    assert 5e-4 < ref_err < 3e-3, ref_err          # the reference's own fp16 error: 1.0e-3 ... 1.4e-3
+    assert 5e-4 < ref_err < 4e-3, ref_err          # the reference's own fp16 error: 0.7e-3 ... 1.4e-3 (one pixel: 3.4e-3)
 
 
 def test_state_dict_contract(golden_dir):

@@ -15,7 +15,8 @@ GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and
 BF16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16ref_") and f.endswith(".npz"))
 # the reference MODULE cast with .half() and run on CPU (tools/make_golden_r2.py, round 6): the reference script's own
 # precision (/root/reference/CODON_X4/test.py:52,122-125)
-FP16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("fp16ref_") and f.endswith(".npz"))
+FP16_REF_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("fp16ref_") and f.endswith(".npz")
+                        and f != "fp16ref_script_sizes.npz")
 
 # the reference MODULE run forward AND backward in bfloat16 on CPU + its float64 twin (tools/make_golden_r4.py)
 BF16_GRAD_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("bf16grad_") and f.endswith(".npz"))

@@ -43,7 +43,22 @@ FP16_CASES = [
     ("fp16ref_he1_x4_1x40x56", "x4", "he1", (1, 40, 56)),
     ("fp16ref_he0_x16_1x33x9", "x16", "he", (1, 33, 9)),
     ("fp16ref_he2_x4_1x370x463", "x4", "he2", (1, 370, 463)),
+    ("fp16ref_kat0_x4_2x32x24", "x4", "kat", (2, 32, 24)),
+    ("fp16ref_kat0_x4_1x1x1", "x4", "kat", (1, 1, 1)),
 ]
+# the Middlebury image sizes the reference script feeds (one image per call, test.py:116-125) with the random inputs of
+# tests/test_gpu_forward.py::test_forward_at_the_reference_scripts_image_sizes: every SUB-th pixel of the reference module's
+# fp16 / fp32 / fp64 outputs (a full image is 1.5 MB; the GPU box's CPU runs fp16 convs two orders of magnitude slower than
+# this container's, so the yardstick is recorded here instead of being recomputed there)
+SCRIPT_SIZES = [(370, 463), (375, 450), (247, 343)]
+SCRIPT_SUB = 7
+
+
+def script_inputs(H, W):
+    g = np.random.default_rng(H)
+    x = torch.from_numpy(g.random((1, 1, H, W), dtype=np.float32))
+    y = torch.from_numpy((g.integers(0, 256, size=(1, 1, H, W)) / 255.0).astype(np.float32))
+    return x, y
 
 
 def main():
@@ -98,7 +113,7 @@ def main():
 
     for name, variant, wkind, (B, H, W) in FP16_CASES:
         net = net_for(variant)
-        sd = orc.he_state(variant, seed=SEEDS[wkind])
+        sd = orc.kat_state(variant) if wkind == "kat" else orc.he_state(variant, seed=SEEDS[wkind])
         x, y = orc.kat_inputs(B, H, W)
         net.float()
         net.load_state_dict(sd, strict=True)
@@ -115,6 +130,31 @@ def main():
         np.savez_compressed(os.path.join(mg.GOLD, name + ".npz"), **rec)
         e = float((oh.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
         print(f"{name}: reference fp16-vs-fp64 rel-RMSE {e:.3e}")
+
+    rec = {"sub": np.int64(SCRIPT_SUB), "sizes": np.array(SCRIPT_SIZES)}
+    net = net_for("x4")
+    for H, W in SCRIPT_SIZES:
+        sd = orc.he_state("x4", seed=70 + H)
+        x, y = script_inputs(H, W)
+        net.float()
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        with torch.no_grad():
+            o32 = net(x, y)
+            o64 = net.double()(x.double(), y.double())
+            oh = net.half()(x.half(), y.half())
+        net.float()
+        net.load_state_dict(sd, strict=True)
+        tag = f"{H}x{W}"
+        rec[tag + ".out_fp64_sub"] = o64.numpy().reshape(-1)[::SCRIPT_SUB]
+        rec[tag + ".out_fp32_sub"] = o32.numpy().reshape(-1)[::SCRIPT_SUB]
+        rec[tag + ".out_fp16_sub"] = oh.numpy().reshape(-1)[::SCRIPT_SUB]
+        e = float((oh.double() - o64).pow(2).mean().sqrt() / o64.pow(2).mean().sqrt())
+        rec[tag + ".ref_err_full"] = np.float64(e)
+        rec[tag + ".x00"] = np.float32(x[0, 0, 0, 0])          # the inputs are regenerated from the seed: a guard against a
+        rec[tag + ".y_last"] = np.float32(y[0, 0, -1, -1])     # numpy whose Generator streams differ
+        print(f"fp16ref_script_sizes {tag}: reference fp16-vs-fp64 rel-RMSE {e:.3e}")
+    np.savez_compressed(os.path.join(mg.GOLD, "fp16ref_script_sizes.npz"), **rec)
 
 
 if __name__ == "__main__":
