@@ -973,23 +973,18 @@ static int launch_pair_c8(const void* av, const void* bv, hipStream_t stream) {
   return check_launch("conv_c8_pair_kernel");
 }
 
-// LAUNCHES OF A FEW ROUNDS (round 6; one image per call, /root/reference/CODON_X4/test.py:116-125).  A CU works through its
-// workgroups at a fixed rate whether one or two are resident (tools/probes/c8_rounds_sweep.py: the chained conv costs 37 us
-// per 256 tiles of 8 x 32 at any count), so a launch takes ceil(tiles / 256) tile times: one 370 x 463 image as a PAIR is
-// 1 410 tiles = 5.5 -> 6.  On 4 x 32 tiles it is 2 790 half-cost tiles = 10.9 -> 11 halves.  The chained conv takes the
-// smaller tile when that is cheaper by this count -- C8_HALF_TILE_COST prices the 4 x 32 tile's extra halo and weight staging
-// (measured, same sweep) -- and never at many rounds, where the 8 x 32 tile's efficiency wins.  Same bits either way.
-constexpr float C8_HALF_TILE_COST = 0.53f;     // one 4 x 32 tile of the chained conv, in 8 x 32 tile times
-static bool c8_chain_half_tiles(const codon_conv_desc* d) {
-  const char* const fe = getenv("CODON_C8_CHAIN_TILE");          // A/B and tests: "4" / "8" force a tile (read per call)
-  const int force = fe ? atoi(fe) : 0;
-  if (force == 4) return true;
-  if (force == 8) return false;
-  const long tx = (d->width + 31) / 32;
-  const long mult = pair_recorder() ? 2 : 1;         // inside a pair bracket the grid holds two such launches
-  const long n8 = tx * ((d->height + 7) / 8) * d->batch * mult, n4 = tx * ((d->height + 3) / 4) * d->batch * mult;
-  if (n8 > 16 * 256) return false;
-  return C8_HALF_TILE_COST * (float)((n4 + 255) / 256) < (float)((n8 + 255) / 256);
+// 4 x 32 TILES FOR LAUNCHES OF A FEW ROUNDS -- measured in round 6 and NOT taken (one image per call,
+// /root/reference/CODON_X4/test.py:116-125).  A CU works through its workgroups at a fixed rate whether one or two are resident
+// (tools/probes/c8_rounds_sweep.py: the chained conv costs 10 + 36 us per started 256 tiles of 8 x 32), so a launch takes
+// ceil(tiles / 256) tile times: one 370 x 463 image as a PAIR is 1 410 tiles = 5.5 -> 6, and on 4 x 32 tiles it would be
+// 2 790 = 10.9 -> 11 half tiles.  But a 4 x 32 tile costs 0.62 of an 8 x 32 one, not 0.5 (tools/probes/c8_tile_ab.py, ten image
+// heights: pair at 370 rows 219.7 -> 248.3 us, lone 113.3 -> 131.2; slower at every height): each workgroup stages the same
+// 20 KB of weights per stage for half the MFMAs, 2 x 24.6 KB per 640 cycles and CU = 77 B/clk against the 64 B/clk a CU draws
+// from L2 (8 x 32: 42 B/clk), and an A fragment serves one pixel row instead of two.  The PS = 1 kernels stay for the
+// tiling-invariance tests (CODON_C8_CHAIN_TILE=4 forces them); the fused statistics are per 4-row strip either way.
+static bool c8_chain_half_tiles(const codon_conv_desc*) {
+  const char* const fe = getenv("CODON_C8_CHAIN_TILE");          // tests / A/B: "4" forces the 4 x 32 tile (read per call)
+  return fe && atoi(fe) == 4;
 }
 
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
