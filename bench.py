@@ -361,7 +361,9 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"CODON x{scale} forward+backward (L1 + SSIM loss, Adam), batch {B}/GPU at {H}x{W}, "
                                    f"{dtype}" + (" activations/gradients, fp32 accumulate + master weights "
-                                                 "(BASELINE.json configs[2] per-GPU shape)" if dtype == "bf16" else ""),
+                                                 "(BASELINE.json configs[2] per-GPU shape)" if dtype == "bf16" else "") +
+                                   "; optimizer = torch.optim.Adam over the 44 fp32 tensors: five ATen multi_tensor_apply launches "
+                                   "(~0.1 ms) per step inside the timed region, every other launch is a codon_* HIP kernel",
                        "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
                        "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
             "images_per_s": world * B * steps / dt,
@@ -385,6 +387,63 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "loss": float(loss.detach()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+
+
+def _timed_ms(fn, dev, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def strong_shards_fwd(model, x, y, dev, full_ms):
+    """one GPU's share of a STRONG-scaling forward (32 images in total over N = 2 / 4 / 8 GPUs).  The forward
+    shards images and has no collective, so the N-GPU strong-scaling time IS the one-GPU time of a 32 / N
+    batch: measurable here, on one GPU.  efficiency(N) = t(b32) / (N t(b32 / N))."""
+    B = x.shape[0]
+    ms = {f"b{B}": full_ms}
+    with torch.no_grad():
+        for n in (2, 4, 8):
+            b = B // n
+            xs, ys = x[:b].contiguous(), y[:b].contiguous()
+            ms[f"b{b}"] = _timed_ms(lambda: model(xs, ys), dev, 3, 1)
+    return {"ms_per_step": ms,
+            "implied_efficiency": {f"n{n}": full_ms / (n * ms[f"b{B // n}"]) for n in (2, 4, 8)},
+            "what": f"fp32 forward of {B} / N images on ONE GPU = a rank's step of --scaling strong at N GPUs (no collective)"}
+
+
+def strong_shards_train(model, x, y, dev, full_ms):
+    """The same for the bf16 training step: forward + L1 + SSIM + backward + Adam on 32 / N images (the flat-gradient all-reduce
+    is the only thing an N-GPU step adds: `step_minus_allreduce_budget_ms` says how long it may take)."""
+    from codon_amd.dist import GradSync
+    from codon_amd.metrics import L1SSIMLoss
+    B = x.shape[0]
+    ms = {f"b{B}": full_ms}
+    model.train()
+    gs = GradSync(model)
+    crit = L1SSIMLoss(1.0, 1.0)
+    for n in (2, 4, 8):
+        b = B // n
+        xs, ys = x[:b].contiguous(), y[:b].contiguous()
+        g = torch.Generator(device=dev); g.manual_seed(7 + n)
+        tgt = torch.rand(xs.shape, generator=g, device=dev)
+        opt = torch.optim.Adam(gs.params, lr=1e-4)
+
+        def step():
+            gs.zero_grad()
+            gs.backward(crit(model(xs, ys).float(), tgt))
+            gs.all_reduce_grads()
+            opt.step()
+
+        ms[f"b{b}"] = _timed_ms(step, dev, 5, 2)
+        del opt
+    eff = {f"n{n}": full_ms / (n * ms[f"b{B // n}"]) for n in (2, 4, 8)}
+    return {"ms_per_step": ms, "implied_efficiency_before_allreduce": eff,
+            "what": f"bf16 training step on {B} / N images on ONE GPU = a rank's compute of --scaling strong at N GPUs"}
 
 
 def _free_port():
@@ -574,6 +633,8 @@ def main():
     ap.add_argument("--rccl-selfcheck", choices=["auto", "on", "off"], default="auto",
                     help="before timing, run SURVEY 8(e)'s gradient-equality check on the product kernels over the process "
                          "group (codon_amd.dist.grad_equality_selfcheck): `grad_equal` in rank 0's line.  auto = when N > 1")
+    ap.add_argument("--no-strong-shards", action="store_true",
+                    help="skip the strong-scaling shard timings (b16 / b8 / b4 on one GPU) of the N = 1 default line")
     ap.add_argument("--no-script-pattern", action="store_true",
                     help="skip the single-image latencies at the reference script's image sizes (N = 1 default line only)")
     a = ap.parse_args()
@@ -748,6 +809,9 @@ def main():
                               "frac_hbm_peak": ALG_ELEMS_PER_PIXEL * esize * P / step_s / 1e9 / PEAK_HBM_GBS,
                               "mpx_per_s": world * P / step_s / 1e6},
         }
+        default_line = world == 1 and (B, H, W, a.scale) == (32, 480, 640, 4) and not bf16 and not split and not rmcr
+        if default_line and not a.no_strong_shards:
+            res["strong_shards"] = {"fwd_fp32": strong_shards_fwd(model, x, y, dev, step_s * 1e3)}
         if world == 1 and not bf16 and not split and a.mode == "fwd" and not rmcr:
             # OPT-IN mode, reported beside (never instead of) the exact-fp32 headline: same inputs, same K steps
             model.set_conv_precision("f16x3")
@@ -801,6 +865,10 @@ def main():
         tm.set_compute_dtype(torch.bfloat16)
         tsteps = 10 if (B, H, W) == (32, 480, 640) else max(3, min(a.steps, 10))     # >= 10 timed iterations
         leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 2, "bf16", a.scale, a.scaling, ctrl=ctrl, data=data)
+        shards_train = None
+        if rank == 0 and res is not None and "strong_shards" in res:
+            torch.cuda.empty_cache()
+            shards_train = strong_shards_train(tm, x, y, dev, leg["ms_per_step"])
         del tm
         torch.cuda.empty_cache()
         if rank == 0:
@@ -813,6 +881,17 @@ def main():
                               "peak_mem_gb": leg["peak_mem_gb"], "step_events": leg["step_events"],
                               "roofline": leg["roofline"], "allreduce_us": leg["allreduce_us"],
                               "allreduce_bytes": leg["allreduce_bytes"], "scaling": leg["scaling"]}
+            if world == 1:
+                t1_ = leg["ms_per_step"]
+                budget = {"weak_8gpu_ge_6x": t1_ * (8.0 / 6.0 - 1.0),
+                          "what": "north_star: >= 6x at 8 GPUs.  Weak scaling (32 images per GPU, the driver's line): the 8-GPU "
+                                  "step may take 8/6 of this one-GPU step, i.e. the RCCL all-reduce of the 7.46 MB gradient "
+                                  "(fwd_bwd.allreduce_us in an N > 1 line) plus any straggler may add this many ms"}
+                if shards_train is not None:
+                    res["strong_shards"]["train_bf16"] = shards_train
+                    budget["strong_8gpu_ge_6x"] = t1_ / 6.0 - shards_train["ms_per_step"]["b4"]
+                    budget["what"] += "; strong scaling (32 images in total): step(b4) + all-reduce must stay below step(b32) / 6"
+                res["fwd_bwd"]["step_minus_allreduce_budget_ms"] = budget
             for r_, st_, hw_ in zip(res["ranks"], leg["per_rank_step_ms"], leg["per_rank_hwmon"]):
                 r_["train_step_ms"] = st_
                 r_["train_power_w_p50"], r_["train_sclk_mhz_p50"] = hw_["power_w_p50"], hw_["sclk_mhz_p50"]
