@@ -283,6 +283,84 @@ def script_pattern_latency(dev):
     return res
 
 
+# the ten image pairs the reference ships for x4 (CODON_X4/input_depth, input_color, input_label: Middlebury crops) -- width x
+# height as PIL reports them, and whether the guidance PNG is RGB (eight of them) or already grey
+SHIPPED_X4 = [("Art", 463, 370, True), ("Books", 463, 370, True), ("Cones", 450, 375, True), ("Dolls", 463, 370, True),
+              ("Laundry", 447, 370, True), ("Moebius", 463, 370, True), ("Reindeer", 447, 370, True), ("Rocks", 425, 370, True),
+              ("Teddy", 450, 375, False), ("Tsukuba", 343, 247, False)]
+
+
+def script_loop_throughput(dev):
+    """the reference script's WHOLE per-image loop (CODON_X4/test.py:109-145: read two PNGs, grey, /255, upload,
+    .half() forward, clip * 255 -> uint8, download, write PNG, masked RMSE + SSIM against the label) over ten image pairs of the
+    shipped x4 set's sizes -- synthetic smooth content written to a scratch directory (the shipped files do not travel), random
+    init (the weights are not shipped).  codon_amd.infer runs it as a pipeline (reader thread + side-stream uploads | forward +
+    metrics | writer thread); the reference-style serial loop is timed beside it (byte-identical outputs:
+    tests/test_extras.py::test_infer_cli_end_to_end)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from codon_amd import CODONNet, infer
+    tmp = tempfile.mkdtemp(prefix="codon_loop_")
+    try:
+        g = np.random.default_rng(0)
+        for d in ("depth", "color", "label", "out_s", "out_p"):
+            os.makedirs(os.path.join(tmp, d))
+
+        def smooth(h, w, c):
+            lo = g.random((h // 8 + 2, w // 8 + 2, c))
+            img = np.kron(lo, np.ones((8, 8, 1)))[:h, :w] * 200 + g.random((h, w, c)) * 55
+            return img.astype(np.uint8)
+
+        for name, w, h, rgb in SHIPPED_X4:
+            Image.fromarray(smooth(h, w, 1)[:, :, 0], mode="L").save(os.path.join(tmp, "depth", name + ".png"))
+            Image.fromarray(smooth(h, w, 1)[:, :, 0], mode="L").save(os.path.join(tmp, "label", name + ".png"))
+            col = smooth(h, w, 3 if rgb else 1)
+            Image.fromarray(col if rgb else col[:, :, 0], mode="RGB" if rgb else "L").save(os.path.join(tmp, "color", name + ".png"))
+        torch.manual_seed(0)
+        m = CODONNet().to(dev).half().eval()
+        kw = dict(input_depth=os.path.join(tmp, "depth"), input_color=os.path.join(tmp, "color"), label=os.path.join(tmp, "label"),
+                  emit=lambda s_: None)
+        res = {"what": "the reference script's per-image loop (test.py:109-145) over 10 PNG pairs of the shipped x4 sizes, "
+                       "model.cuda().half(), outputs written, RMSE + SSIM vs the label; whole loop wall time incl. PNG "
+                       "decode / encode on the host; second pass of two (first pass warms allocator and page cache)",
+               "images": len(SHIPPED_X4), "data": "synthetic PNGs at the shipped sizes (8 RGB + 2 grey guidance images)"}
+        for tag, pipe, od in (("serial", False, "out_s"), ("pipelined", True, "out_p")):
+            best = None
+            for _ in range(2):
+                r = infer.run_loop(m, dev, torch.float16, out_dir=os.path.join(tmp, od), pipelined=pipe, **kw)
+                best = r
+            res[f"{tag}_images_per_s"] = best["images_per_s"]
+            res[f"{tag}_ms_per_image"] = 1e3 * best["seconds"] / best["n"]
+        res["script_loop_images_per_s"] = res["pipelined_images_per_s"]
+        same = all(open(os.path.join(tmp, "out_s", n + ".png"), "rb").read() == open(os.path.join(tmp, "out_p", n + ".png"), "rb").read()
+                   for n, _, _, _ in SHIPPED_X4)
+        res["outputs_byte_identical_to_serial"] = bool(same)
+        # the same loop's forward on the CPU oracle (fp32, as BASELINE configs[0] runs the reference): three of the ten sizes
+        # timed, scaled to the ten images by pixel count -- the forward alone (the CPU loop's I/O is the same host code)
+        from oracle import codon_oracle as orc
+        threads = int(os.environ.get("CODON_CPU_THREADS", str(min(os.cpu_count() or 1, 16))))
+        torch.set_num_threads(threads)
+        sd = orc.he_state("x4", seed=0)
+        sample = [(370, 463), (375, 450), (247, 343)]
+        t_cpu, px = 0.0, 0
+        with torch.no_grad():
+            for h, w in sample:
+                x1, y1 = torch.rand((1, 1, h, w)), torch.rand((1, 1, h, w))
+                t0 = time.perf_counter()
+                orc.forward(sd, x1, y1)
+                t_cpu += time.perf_counter() - t0
+                px += h * w
+        total_px = sum(w * h for _, w, h, _ in SHIPPED_X4)
+        res["cpu_oracle_loop_seconds_est"] = t_cpu * total_px / px
+        res["cpu_oracle"] = {"kind": "port", "cores": threads, "sample": "one fp32 forward each at 370x463, 375x450, 247x343 "
+                             f"({t_cpu:.1f} s), scaled by pixel count to the ten images"}
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype, scale, scaling="weak", ctrl=None,
               data=None):
     """One step = zero_grad, forward, L1 + (1 - SSIM) loss (HIP kernels, forward and backward), backward (HIP
@@ -902,6 +980,9 @@ def main():
                 res["config0_on_gpu"] = config0_gpu_latency(dev)
                 if not a.no_script_pattern:
                     res["script_pattern_on_gpu"] = script_pattern_latency(dev)
+                    res["script_pattern_on_gpu"]["script_loop"] = script_loop_throughput(dev)
+                    res["script_pattern_on_gpu"]["script_loop_images_per_s"] = \
+                        res["script_pattern_on_gpu"]["script_loop"]["script_loop_images_per_s"]
         if probe is not None and probe.get("any_rank_hung"):
             # a helper thread was still stuck inside an RCCL collective on some rank while the legs were timed --
             # it may have held CUs.  The line says so and the process exits with EXIT_RCCL_HUNG: a driver that looks at the

@@ -1,19 +1,141 @@
 """python -m codon_amd.infer -- the reference's test loop (CODON_X4/test.py:60-145) on MI355X:
 for every image: read depth (already HR-sized) + guidance, forward, clip/*255/uint8, write PNG, masked RMSE
 vs the label, SSIM vs the label; print per-image values and the means.  Everything numeric runs in HIP kernels
-(codon_amd.CODONNet, codon_amd.metrics); this file is I/O glue."""
+(codon_amd.CODONNet, codon_amd.metrics); this file is I/O glue.
+
+Round 6: the loop is a PIPELINE.  One forward of a Middlebury image takes 2.3 ms; decoding its two PNGs, the float
+conversion, the upload, the download and the PNG encode take several times that on the host, and the reference's loop
+(test.py:109-145) does all of it serially per image.  Here
+  reader thread : decode image i+1 (PIL releases the GIL), /255, cast, pinned host tensors, upload on a SIDE stream
+  main thread   : forward + post-processing + metrics of image i on the caller's stream (waits for the upload's event)
+  writer thread : download of image i-1 has landed in pinned memory (event) -> PNG encode + write
+Same arithmetic per image in the same order: outputs are byte-identical to the serial loop (`--serial`, kept for the A/B
+and the test)."""
 from __future__ import annotations
 
 import argparse
 import os
+import queue
+import threading
+import time
 
 import torch
 
 from . import CODONNet, CODONNet16, io, metrics
 
 
+def list_pairs(input_depth: str, input_color: str):
+    return [f for f in sorted(os.listdir(input_color)) if os.path.exists(os.path.join(input_depth, f))]
+
+
+def _load_host(a_depth, a_color, a_label, f, tdt):
+    """Host side of one image: decode, grey, /255 (float64 divide, then float32: test.py:116-123), crop both to the common
+    size, cast to the model's dtype (the rounding `.cuda().half()` does on the device, done here on half the bytes)."""
+    x = io.to_input(io.read_gray(os.path.join(a_depth, f)))
+    y = io.to_input(io.read_gray(os.path.join(a_color, f)))
+    h, w = min(x.shape[2], y.shape[2]), min(x.shape[3], y.shape[3])
+    x, y = x[:, :, :h, :w].contiguous().to(tdt), y[:, :, :h, :w].contiguous().to(tdt)
+    lab = torch.from_numpy(io.read_gray(os.path.join(a_label, f)).copy()) if a_label else None
+    return x, y, lab, h, w
+
+
+def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None, pipelined=True, emit=print, files=None):
+    """The test loop over every image pair.  Returns {"n", "rmse_mean", "ssim_mean", "seconds", "images_per_s"}."""
+    files = list_pairs(input_depth, input_color) if files is None else files
+    t0 = time.perf_counter()
+    rm_sum = ss_sum = 0.0
+    n = 0
+
+    def finish(f, out, lab, h, w):
+        nonlocal rm_sum, ss_sum, n
+        out_u8 = metrics.postprocess_u8(out[0, 0])
+        line = f
+        if lab is not None:
+            rm = metrics.masked_rmse(lab, out_u8)
+            ss = metrics.ssim(lab[:h, :w].float() / 255, out_u8.float() / 255)
+            rm_sum += rm; ss_sum += ss
+            line += f" {rm} {ss}"
+        n += 1
+        return out_u8, line
+
+    if not pipelined:
+        for f in files:
+            x, y, lab, h, w = _load_host(input_depth, input_color, label, f, tdt)
+            with torch.no_grad():
+                out = model(x.to(dev), y.to(dev))
+            out_u8, line = finish(f, out, lab.to(dev) if lab is not None else None, h, w)
+            if out_dir:
+                io.write_gray(os.path.join(out_dir, f), out_u8.cpu().numpy())
+            emit(line)
+    else:
+        main_s = torch.cuda.current_stream(dev)
+        up_s = torch.cuda.Stream(device=dev)
+        q_in: "queue.Queue" = queue.Queue(maxsize=3)
+        q_out: "queue.Queue" = queue.Queue(maxsize=4)
+        errs = []
+
+        def reader():
+            try:
+                torch.cuda.set_device(dev)
+                for f in files:
+                    x, y, lab, h, w = _load_host(input_depth, input_color, label, f, tdt)
+                    host = [t.pin_memory() for t in (x, y)] + ([lab.pin_memory()] if lab is not None else [])
+                    with torch.cuda.stream(up_s):
+                        devs = [t.to(dev, non_blocking=True) for t in host]
+                        ev = torch.cuda.Event()
+                        ev.record(up_s)
+                    q_in.put((f, devs, host, ev, h, w))          # `host` rides along: pinned sources stay alive until consumed
+            except BaseException as e:      # noqa: BLE001 -- re-raised in the main thread
+                errs.append(e)
+            finally:
+                q_in.put(None)
+
+        def writer():
+            try:
+                while True:
+                    item = q_out.get()
+                    if item is None:
+                        return
+                    f, host_u8, ev = item
+                    ev.synchronize()                               # the download of this image has landed
+                    if out_dir:
+                        io.write_gray(os.path.join(out_dir, f), host_u8.numpy())
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+
+        tr, tw = threading.Thread(target=reader, name="codon_infer_reader"), threading.Thread(target=writer, name="codon_infer_writer")
+        tr.start(); tw.start()
+        try:
+            while True:
+                item = q_in.get()
+                if item is None:
+                    break
+                f, devs, _host, ev, h, w = item
+                main_s.wait_event(ev)
+                for t in devs:
+                    t.record_stream(main_s)                        # allocated on the upload stream, consumed on this one
+                with torch.no_grad():
+                    out = model(devs[0], devs[1])
+                out_u8, line = finish(f, out, devs[2] if len(devs) > 2 else None, h, w)
+                host_u8 = torch.empty(out_u8.shape, dtype=torch.uint8).pin_memory()
+                host_u8.copy_(out_u8, non_blocking=True)
+                dv = torch.cuda.Event()
+                dv.record(main_s)
+                q_out.put((f, host_u8, dv))
+                emit(line)
+        finally:
+            q_out.put(None)
+            tr.join(); tw.join()
+        if errs:
+            raise errs[0]
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"n": n, "rmse_mean": rm_sum / n if (label and n) else None, "ssim_mean": ss_sum / n if (label and n) else None,
+            "seconds": dt, "images_per_s": n / dt if dt > 0 else 0.0}
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__)
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8, 16])
     ap.add_argument("--input-depth", required=True)
     ap.add_argument("--input-color", required=True)
@@ -21,6 +143,8 @@ def main(argv=None):
     ap.add_argument("--out", default=None)
     ap.add_argument("--weights", default=None, help="X4.pth-style checkpoint; random reference init if absent")
     ap.add_argument("--dtype", default="f16", choices=["f32", "bf16", "f16"], help="the reference script runs .half()")
+    ap.add_argument("--serial", action="store_true", help="the reference's own serial loop (decode, upload, forward, download, "
+                                                          "encode one after the other per image) instead of the pipeline")
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("No GPU found, codon_amd has no CPU path")          # test.py:37-38
@@ -34,32 +158,10 @@ def main(argv=None):
     model = model.to(dev).to(tdt).eval()
     if a.out:
         os.makedirs(a.out, exist_ok=True)
-    rm_sum = ss_sum = 0.0
-    n = 0
-    for f in sorted(os.listdir(a.input_color)):
-        dpath = os.path.join(a.input_depth, f)
-        if not os.path.exists(dpath):
-            continue
-        x = io.to_input(io.read_gray(dpath)).to(dev).to(tdt)
-        y = io.to_input(io.read_gray(os.path.join(a.input_color, f))).to(dev).to(tdt)
-        h, w = min(x.shape[2], y.shape[2]), min(x.shape[3], y.shape[3])
-        with torch.no_grad():
-            out = model(x[:, :, :h, :w].contiguous(), y[:, :, :h, :w].contiguous())
-        out_u8 = metrics.postprocess_u8(out[0, 0])
-        if a.out:
-            io.write_gray(os.path.join(a.out, f), out_u8.cpu().numpy())
-        line = f
-        if a.label:
-            lab = torch.from_numpy(io.read_gray(os.path.join(a.label, f)).copy()).to(dev)
-            rm = metrics.masked_rmse(lab, out_u8)
-            ss = metrics.ssim(lab[:h, :w].float() / 255, out_u8.float() / 255)
-            rm_sum += rm; ss_sum += ss
-            line += f" {rm} {ss}"
-        print(line)
-        n += 1
-    print(n)
-    if a.label and n:
-        print(rm_sum / n, ss_sum / n)
+    r = run_loop(model, dev, tdt, a.input_depth, a.input_color, a.label, a.out, pipelined=not a.serial)
+    print(r["n"])
+    if a.label and r["n"]:
+        print(r["rmse_mean"], r["ssim_mean"])
     return 0
 
 

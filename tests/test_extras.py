@@ -174,14 +174,21 @@ def test_cross_ablation_matches_oracle_restatement(shape, seed):
 
 
 @pytest.mark.gpu
-def test_infer_cli_end_to_end(tmp_path):
+def test_infer_cli_end_to_end(tmp_path, capsys):
     """The reference's test loop on synthetic PNGs: runs, writes outputs, prints metrics; with zeroed
-    output.weight the network is the identity on the depth map, so RMSE/SSIM vs the depth itself are 0 / 1."""
+    output.weight the network is the identity on the depth map, so RMSE/SSIM vs the depth itself are 0 / 1.
+    Round 6: the loop is a three-stage pipeline (reader thread + side-stream uploads, forward, writer thread); its PNGs and
+    printed metrics must be byte-identical to the reference-style serial loop (`--serial`), in fp32 and in the script's fp16."""
     from codon_amd import CODONNet, infer, io
     g = np.random.default_rng(0)
     for d in ("depth", "color", "label", "out"):
         os.makedirs(tmp_path / d)
-    for name, (h, w) in (("a.png", (40, 56)), ("b.png", (33, 47))):
+    sizes = (("a.png", (40, 56)), ("b.png", (33, 47)), ("c.png", (64, 40)), ("d.png", (33, 47)), ("e.png", (17, 90)))
+    for name, (h, w) in sizes[2:]:          # more images than the queues hold, with repeated and changing sizes
+        io.write_gray(str(tmp_path / "depth" / name), g.integers(1, 256, (h, w)).astype(np.uint8))
+        io.write_gray(str(tmp_path / "label" / name), g.integers(0, 256, (h + 2, w + 1)).astype(np.uint8))
+        io.write_gray(str(tmp_path / "color" / name), g.integers(0, 256, (h, w + 3)).astype(np.uint8))
+    for name, (h, w) in sizes[:2]:
         dep = g.integers(1, 256, (h, w)).astype(np.uint8)
         io.write_gray(str(tmp_path / "depth" / name), dep)
         io.write_gray(str(tmp_path / "label" / name), dep)
@@ -199,3 +206,20 @@ def test_infer_cli_end_to_end(tmp_path):
         dep = io.read_gray(str(tmp_path / "depth" / name))
         # identity network: uint8(clip(x/255)*255) reproduces x except where float32(x/255)*255 rounds below x
         assert np.abs(out.astype(int) - dep.astype(int)).max() <= 1
+    # pipeline == serial loop, byte for byte, with a network that is NOT the identity
+    torch.manual_seed(5)
+    ck2 = str(tmp_path / "X4b.pth")
+    torch.save({"epoch": 2, "model": CODONNet()}, ck2)
+    for dt in ("f32", "f16"):
+        outs = {}
+        for mode in ("serial", "pipe"):
+            od = tmp_path / f"out_{dt}_{mode}"
+            capsys.readouterr()
+            rc = infer.main(["--scale", "4", "--input-depth", str(tmp_path / "depth"), "--input-color", str(tmp_path / "color"),
+                             "--label", str(tmp_path / "label"), "--out", str(od), "--weights", ck2, "--dtype", dt] +
+                            (["--serial"] if mode == "serial" else []))
+            assert rc == 0
+            outs[mode] = (capsys.readouterr().out, {n: open(od / n, "rb").read() for n, _ in sizes})
+        assert outs["serial"][0] == outs["pipe"][0] and len(outs["pipe"][0].splitlines()) == 1 + len(sizes) + 2
+        assert outs["serial"][1] == outs["pipe"][1]
+        assert len({bytes(v) for v in outs["pipe"][1].values()}) == len(sizes)          # five different images came out
