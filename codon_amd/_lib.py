@@ -158,7 +158,12 @@ def load():
             raise RuntimeError(
                 f"codon_amd: {path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C codon_amd/csrc`. There is no CPU or eager fallback.")
-        lib = C.CDLL(path)
+        # PyDLL: the entry points are called WITH the interpreter lock held.  Every one of them is an asynchronous launch (or
+        # host arithmetic) of a few microseconds; releasing and re-taking the lock around each -- what CDLL does -- hands it
+        # to any other thread that wants it ~50 times per forward, and the launching thread then queues for it behind that
+        # thread's whole time slice (measured: the pipelined test loop of codon_amd.infer ran SLOWER than the serial one,
+        # 111 vs 142 images/s, with CDLL).  torch's own blocking calls (synchronize, .item()) still release the lock.
+        lib = C.PyDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res

@@ -14,6 +14,7 @@ and the test)."""
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import queue
 import threading
@@ -103,8 +104,24 @@ def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None
             except BaseException as e:      # noqa: BLE001
                 errs.append(e)
 
+        def settle(pend):
+            """Metrics of an image whose launches were enqueued one image ago: its three numbers have been downloaded behind
+            its kernels; the same host arithmetic as metrics.masked_rmse / metrics.ssim."""
+            nonlocal rm_sum, ss_sum, n
+            f, h_acc, h_ss, ev = pend
+            line = f
+            if h_acc is not None:
+                ev.synchronize()
+                s_, c_ = (int(v) for v in h_acc)
+                rm, ss = math.sqrt(s_ / c_), float(h_ss.item())
+                rm_sum += rm; ss_sum += ss
+                line += f" {rm} {ss}"
+            n += 1
+            emit(line)
+
         tr, tw = threading.Thread(target=reader, name="codon_infer_reader"), threading.Thread(target=writer, name="codon_infer_writer")
         tr.start(); tw.start()
+        pending = None
         try:
             while True:
                 item = q_in.get()
@@ -116,13 +133,25 @@ def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None
                     t.record_stream(main_s)                        # allocated on the upload stream, consumed on this one
                 with torch.no_grad():
                     out = model(devs[0], devs[1])
-                out_u8, line = finish(f, out, devs[2] if len(devs) > 2 else None, h, w)
+                out_u8 = metrics.postprocess_u8(out[0, 0])
+                h_acc = h_ss = None
+                if len(devs) > 2:                                  # metrics stay on the device; read back one image later
+                    lab = devs[2]
+                    acc = metrics.masked_sqerr_dev(lab, out_u8)
+                    ssv = metrics.ssim_dev(lab[:h, :w].float() / 255, out_u8.float() / 255)
+                    h_acc, h_ss = torch.empty(2, dtype=torch.int64).pin_memory(), torch.empty(1, dtype=torch.float64).pin_memory()
+                    h_acc.copy_(acc, non_blocking=True)
+                    h_ss.copy_(ssv, non_blocking=True)
                 host_u8 = torch.empty(out_u8.shape, dtype=torch.uint8).pin_memory()
                 host_u8.copy_(out_u8, non_blocking=True)
                 dv = torch.cuda.Event()
                 dv.record(main_s)
                 q_out.put((f, host_u8, dv))
-                emit(line)
+                if pending is not None:
+                    settle(pending)                                # image i-1, while image i runs
+                pending = (f, h_acc, h_ss, dv)
+            if pending is not None:
+                settle(pending)
         finally:
             q_out.put(None)
             tr.join(); tw.join()

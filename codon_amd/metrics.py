@@ -34,9 +34,9 @@ def postprocess_u8(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def masked_rmse(label_u8: torch.Tensor, out_u8: torch.Tensor) -> float:
-    """test.py::EvaluationResults: label is cropped to the output's size (:151); pixels with label == 0 are
-    excluded from both the error and the count."""
+def masked_sqerr_dev(label_u8: torch.Tensor, out_u8: torch.Tensor) -> torch.Tensor:
+    """masked_rmse's two exact integer sums as a DEVICE tensor int64[2] = { sum of squared errors, count } -- no host
+    synchronisation (codon_amd.infer reads them back one image later); rmse = sqrt(s / c)."""
     lib = L.load()
     assert label_u8.dtype == torch.uint8 and out_u8.dtype == torch.uint8 and out_u8.dim() == 2
     label_u8 = label_u8[:out_u8.shape[0], :out_u8.shape[1]].contiguous()
@@ -46,7 +46,13 @@ def masked_rmse(label_u8: torch.Tensor, out_u8: torch.Tensor) -> float:
     with torch.cuda.device(dev):
         L.check(lib.codon_masked_sqerr(out_u8.numel(), _p(label_u8), _p(out_u8), _p(acc), ops._stream(dev)),
                 "masked_sqerr")
-    s, c = (int(v) for v in acc.cpu())
+    return acc
+
+
+def masked_rmse(label_u8: torch.Tensor, out_u8: torch.Tensor) -> float:
+    """test.py::EvaluationResults: label is cropped to the output's size (:151); pixels with label == 0 are
+    excluded from both the error and the count."""
+    s, c = (int(v) for v in masked_sqerr_dev(label_u8, out_u8).cpu())
     return math.sqrt(s / c)
 
 
@@ -63,12 +69,17 @@ def _ssim_forward(a, b, want_maps):
     return val, dmaps
 
 
-def ssim(a: torch.Tensor, b: torch.Tensor) -> float:
-    """mean SSIM of two (B,1,H,W) or (H,W) fp32 images in [0,1] (ssim_exact's definition)."""
+def ssim_dev(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """ssim() as a DEVICE tensor float64[1]: no host synchronisation."""
     if a.dim() == 2:
         a, b = a[None, None], b[None, None]
     v, _ = _ssim_forward(a.float().contiguous(), b.float().contiguous(), False)
-    return float(v.item())
+    return v
+
+
+def ssim(a: torch.Tensor, b: torch.Tensor) -> float:
+    """mean SSIM of two (B,1,H,W) or (H,W) fp32 images in [0,1] (ssim_exact's definition)."""
+    return float(ssim_dev(a, b).item())
 
 
 class _L1SSIMFn(torch.autograd.Function):
