@@ -20,6 +20,7 @@ import queue
 import threading
 import time
 
+import numpy as np
 import torch
 
 from . import CODONNet, CODONNet16, io, metrics
@@ -32,12 +33,21 @@ def list_pairs(input_depth: str, input_color: str):
 def _load_host(a_depth, a_color, a_label, f, tdt):
     """Host side of one image: decode, grey, /255 (float64 divide, then float32: test.py:116-123), crop both to the common
     size, cast to the model's dtype (the rounding `.cuda().half()` does on the device, done here on half the bytes)."""
-    x = io.to_input(io.read_gray(os.path.join(a_depth, f)))
-    y = io.to_input(io.read_gray(os.path.join(a_color, f)))
-    h, w = min(x.shape[2], y.shape[2]), min(x.shape[3], y.shape[3])
-    x, y = x[:, :, :h, :w].contiguous().to(tdt), y[:, :, :h, :w].contiguous().to(tdt)
+    # numpy only (single-threaded): torch's CPU ops fan a 170 k-element conversion out over every host core, which costs
+    # milliseconds per call on a 128-core box; the values are io.to_input()'s -- float64 divide, float32, then the dtype's
+    # round-to-nearest-even -- bit for bit
+    px = io.read_gray(os.path.join(a_depth, f))
+    py = io.read_gray(os.path.join(a_color, f))
+    h, w = min(px.shape[0], py.shape[0]), min(px.shape[1], py.shape[1])
+    ndt = {torch.float32: np.float32, torch.float16: np.float16}.get(tdt)
+
+    def conv(p_):
+        v = (np.asarray(p_[:h, :w]) / 255).astype(np.float32)
+        t = torch.from_numpy(np.ascontiguousarray(v.astype(ndt) if ndt is not None else v))[None, None]
+        return t if ndt is not None else t.to(tdt)          # bf16 has no numpy type
+
     lab = torch.from_numpy(io.read_gray(os.path.join(a_label, f)).copy()) if a_label else None
-    return x, y, lab, h, w
+    return conv(px), conv(py), lab, h, w
 
 
 def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None, pipelined=True, emit=print, files=None):
