@@ -50,6 +50,9 @@ def _load_host(a_depth, a_color, a_label, f, tdt):
     return conv(px), conv(py), lab, h, w
 
 
+READERS = int(os.environ.get("CODON_INFER_READERS", "3"))
+
+
 def _pinned_copy(t: torch.Tensor) -> torch.Tensor:
     """t in page-locked memory, filled by a numpy copy: Tensor.pin_memory() copies with an at::parallel_for, i.e. spins up an
     OpenMP team of every host core in whichever thread calls it first (measured on the 128-core GPU box: 130 ms per image in a
@@ -93,14 +96,20 @@ def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None
     else:
         main_s = torch.cuda.current_stream(dev)
         up_s = torch.cuda.Stream(device=dev)
-        q_in: "queue.Queue" = queue.Queue(maxsize=3)
+        # READERS reader threads take every READERS-th image each (decoding two PNGs is the longest stage: 3.1 ms against a
+        # 2.3 ms forward); the main thread takes their queues in turn, so images are consumed in order
+        q_ins = [queue.Queue(maxsize=2) for _ in range(READERS)]
         q_out: "queue.Queue" = queue.Queue(maxsize=4)
         errs = []
+        stop = threading.Event()
 
-        def reader():
+        def reader(k):
+            q_in = q_ins[k]
             try:
                 torch.cuda.set_device(dev)
-                for f in files:
+                for f in files[k::READERS]:
+                    if stop.is_set():
+                        break
                     x, y, lab, h, w = _load_host(input_depth, input_color, label, f, tdt)
                     host = [_pinned_copy(t) for t in ((x, y) if lab is None else (x, y, lab))]
                     with torch.cuda.stream(up_s):
@@ -141,13 +150,15 @@ def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None
             n += 1
             emit(line)
 
-        tr, tw = threading.Thread(target=reader, name="codon_infer_reader"), threading.Thread(target=writer, name="codon_infer_writer")
-        tr.start(); tw.start()
+        trs = [threading.Thread(target=reader, args=(k,), name=f"codon_infer_reader{k}") for k in range(READERS)]
+        tw = threading.Thread(target=writer, name="codon_infer_writer")
+        for t_ in trs + [tw]:
+            t_.start()
         pending = None
         try:
-            while True:
-                item = q_in.get()
-                if item is None:
+            for i in range(len(files)):
+                item = q_ins[i % READERS].get()
+                if item is None:                                   # that reader failed: its error is re-raised below
                     break
                 f, devs, _host, ev, h, w = item
                 main_s.wait_event(ev)
@@ -177,7 +188,15 @@ def run_loop(model, dev, tdt, input_depth, input_color, label=None, out_dir=None
                 settle(pending)
         finally:
             q_out.put(None)
-            tr.join(); tw.join()
+            stop.set()
+            for t_, q_ in zip(trs, q_ins):                         # error paths: a reader may be blocked on a full queue
+                while t_.is_alive():
+                    try:
+                        q_.get_nowait()
+                    except queue.Empty:
+                        pass
+                    t_.join(0.02)
+            tw.join()
         if errs:
             raise errs[0]
     torch.cuda.synchronize(dev)
