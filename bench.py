@@ -57,11 +57,20 @@ def synth_inputs(B, H, W, scale, seed, dev):
     return x.contiguous(), y.contiguous()
 
 
+# profiled workloads other than 32 x 480 x 640 (round 6: BASELINE configs[3] and [4]): (B, H, W) -> PMC table pattern
+PMC_SHAPES = {(16, 960, 1280): "r*_x8_fwd_b16_960x1280_pmc.json", (8, 1920, 2560): "r*_x16_bf16_fwd_b8_1920x2560_pmc.json"}
+
+
+def pmc_pattern(B, H, W, default):
+    return default if (B, H, W) == (32, 480, 640) else PMC_SHAPES.get((B, H, W))
+
+
 def pmc_traffic(kernel_prefix, B, H, W, pattern="r*_fwd_b32_480x640_pmc*.json"):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/: FETCH_SIZE x2-corrected +
     WRITE_SIZE, separate passes of the same bench command).  Counters cannot be read from inside this process, so this
     is the latest committed measurement for this exact workload, or None."""
-    if (B, H, W) != (32, 480, 640):
+    pattern = pmc_pattern(B, H, W, pattern)
+    if pattern is None:
         return None
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
@@ -876,7 +885,8 @@ def main():
                                      None if split else pmc_traffic("codon::conv_mfma_f32_kernel<5, 128, 128", B, H, W)),
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "traffic_from_hash": None if split else pmc_traffic_hash(
-                             "r*_bf16_fwd_b32_480x640_pmc.json" if bf16 else "r*_fwd_b32_480x640_pmc*.json")[0],
+                             pmc_pattern(B, H, W, "r*_bf16_fwd_b32_480x640_pmc.json" if bf16 else "r*_fwd_b32_480x640_pmc*.json")
+                             or "none")[0],
                          "lib_source_hash": pmc_traffic_hash()[1],
                          "alg_bytes_per_launch": (128 + 64 if chained else 2 * 128) * esize * P,
                          "launches_timed": len(ev), "avg_launch_ms": kms,

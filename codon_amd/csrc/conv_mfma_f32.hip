@@ -125,7 +125,7 @@ enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false,
           bool ST = false>
 __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid) {
-  static_assert(!CSPLIT || (PSEG == 1 && NW == 4 && COUT % 64 == 0 && !GATE), "the cout-split form is a small-grid plain / chained conv");
+  static_assert(!CSPLIT || (PSEG == 1 && NW == 4 && COUT % 64 == 0), "the cout-split form is a small-grid conv");
   static_assert(!ST || FUSE, "statistics come out of the chained 1x1's epilogue");
   constexpr int NT = NW * 64;
   constexpr int PAD = KS / 2;
@@ -761,12 +761,12 @@ static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
   return check_launch("conv_mfma_f32_pair_kernel");
 }
 // a cout-split launch: held back by an open pair bracket, else alone with a CU per workgroup
-template <int KS, int CIN, int COUT, bool FUSE, int NW, bool ST = false>
+template <int KS, int CIN, int COUT, bool FUSE, int NW, bool ST = false, bool GATE = false>
 static int launch_or_hold_csplit_f32(const ConvParams& p, hipStream_t stream) {
-  if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>,
-                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>, stream))
+  if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>,
+                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>, stream))
     return held < 0 ? held : CODON_OK;
-  return launch_single_f32<KS, CIN, COUT, 1, FUSE, false, NW, true, true, ST>(&p, stream);
+  return launch_single_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>(&p, stream);
 }
 // small-grid launches (PSEG = 1) can be held back by an open pair bracket; everything else launches at once
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE, bool GATE, int NW, bool ST = false>
@@ -844,11 +844,11 @@ int conv_tiling_f32(const codon_conv_desc* d, int chained, int in_pair) {
   return CODON_TILING_4X32_SOLO;
 }
 
-template <int KS, int CIN, int COUT, int PSEG>
+template <int KS, int CIN, int COUT, int PSEG, bool CSPLIT = false>
 static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
                           const float* sp, const float* w, float* y, const codon_tensor* gated_out, bool solo,
                           hipStream_t stream) {
-  constexpr int TH = 4 * PSEG;
+  constexpr int TH = (CSPLIT ? 2 : 4) * PSEG;
   ConvParams p;
   p.x = pre; p.w = w; p.y = y; p.res = nullptr;
   p.H = d->height; p.W = d->width;
@@ -872,6 +872,7 @@ static int launch_gated_p(const codon_conv_desc* d, const float* pre, const codo
 #ifdef CODON_TIMING
   p.dbg = codon_dbg_ptr();
 #endif
+  if constexpr (CSPLIT) return launch_or_hold_csplit_f32<KS, CIN, COUT, false, 4, false, true>(p, stream);
   return launch_or_hold_f32<KS, CIN, COUT, PSEG, false, true, 4>(p, PSEG == 1 && solo, stream);
 }
 
@@ -879,6 +880,14 @@ template <int KS, int CIN, int COUT>
 static int launch_gated(const codon_conv_desc* d, const float* pre, const codon_tensor* in2, const float* ch,
                         const float* sp, const float* w, float* y, const codon_tensor* gated_out, hipStream_t stream) {
   const GridMode mode = KS == 5 ? grid_mode(d, GRID_SOLO_CONV64) : small_grid(d) ? GRID_4X32_SOLO : GRID_8X32;
+  if (mode == GRID_4X32_SOLO) {
+    // round 6: the gated convs of a small launch take the cout split too (one 128 x 128 image: conv7 alone is 128 tiles whose
+    // waves each run 1 152 MFMAs back to back; the gated 5x5 pairs 1 600) -- the staging arithmetic is the workgroup's, the split
+    // only divides the MFMA chain; same fma chain per output: same bits
+    const long nblk4 = (long)((d->width + 31) / 32) * ((d->height + 3) / 4) * d->batch;
+    if (nblk4 <= (pair_recorder() ? CSPLIT_PAIR_MAX_BLOCKS : CSPLIT_MAX_BLOCKS))
+      return launch_gated_p<KS, CIN, COUT, 1, true>(d, pre, in2, ch, sp, w, y, gated_out, true, stream);
+  }
   if (mode != GRID_8X32) return launch_gated_p<KS, CIN, COUT, 1>(d, pre, in2, ch, sp, w, y, gated_out, mode == GRID_4X32_SOLO, stream);
   return launch_gated_p<KS, CIN, COUT, 2>(d, pre, in2, ch, sp, w, y, gated_out, false, stream);
 }

@@ -250,8 +250,12 @@ template <typename T>
 static int stem_launch(int B, int H, int W, const float* x, const float* w, T* y, int y_ctotal, int y_coff, int flags,
                        const T* mask, int m_ctotal, int m_coff, hipStream_t stream) {
   const long HW = (long)H * W;
-  const bool v4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
-                                    reinterpret_cast<uintptr_t>(mask)) % 16 == 0);
+  // images of a few thousand pixels (one 128 x 128 pair per call, BASELINE configs[0]): the four-pixel form is 16 workgroups
+  // on 256 CUs, each thread 64 dependent row stores long -- the one-pixel form has four times the threads.  Same fma chain
+  // per output either way: same bits.
+  const bool tiny = (long)B * H * W <= 65536;
+  const bool v4 = !tiny && (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                             reinterpret_cast<uintptr_t>(mask)) % 16 == 0);
   const long total = (long)B * H * (v4 ? W / 4 : W);
   const long blocks = (total + 255) / 256;
   CODON_REQUIRE(blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "stem_fwd: grid too large");
@@ -316,6 +320,9 @@ static int head_launch(int B, int H, int W, const T* x, int x_ctotal, int x_coff
   // fp32 R = 4 / 8 / 16: 0.531 / 0.468 / 0.462 ms; bf16: 0.429 / 0.393 / 0.345 ms (round 1: 1.11 / 1.30 ms).  Small
   // images keep R = 4 (more waves).
   const bool big = (long)B * H * W >= (1L << 22);
+  // a few thousand pixels (one 128 x 128 image: 32 waves of the 4-pixel form, each 16 memory round trips long): one row and
+  // 64 pixels per wave, 16 channels' rows in flight -- 256 waves, 4 round trips.  Same accumulation order: same bits.
+  if ((long)B * H * W <= 65536) return head_launch_v<1, 1, T, 16>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);
   if (v4)
     return big ? head_launch_v<4, 16, T>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream)
                : head_launch_v<4, 4, T, 4>(B, H, W, x, x_ctotal, x_coff, w, res, y, stream);

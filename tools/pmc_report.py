@@ -59,7 +59,7 @@ def load(d, counters):
 def alg_bytes(name, P, es, mode):
     """(bytes the kernel must move once per launch, role note) or (None, reason)."""
     train = mode == "train"
-    m = re.match(r"conv_c8_kernel<C8\w+, (\d), (\d+), (\d+), (true|false)(?:, \d+, (true|false))?(?:, (?:true|false), (?:true|false))?>", name)
+    m = re.match(r"conv_c8_kernel<C8\w+, (\d), (\d+), (\d+), (true|false)(?:, \d+, (true|false))?(?:, (?:true|false), (?:true|false))?(?:, \d+)?>", name)
     if m:
         k, ci, co, fuse, gate = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true", m.group(5) == "true"
         if fuse:      # conv5x5 + chained 1x1: 128 in + 64 out; a training step also writes the 128-channel mid

@@ -17,14 +17,16 @@ run() {   # run <name> <bench args...>: JSON line -> <tag>_<name>.json, stderr -
   echo "== $name"; $B "$@" > $OUT/${tag}_${name}.json 2> $OUT/${tag}_${name}.err
 }
 pmc3() {  # pmc3 <label> <out.json> <mode> <esize> <bench args...>: FETCH / WRITE / busy passes + the merged table
+  # (PMC_SHAPE="B H W" for a profiled command that is not 32 x 480 x 640)
   local label=$1 out=$2 mode=$3 es=$4; shift 4
+  local shape=${PMC_SHAPE:-32 480 640}
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== $label: pmc $c"
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${tag}_${label}_$c -- python3 $ROOT/bench.py "$@" --steps 1 --warmup 0 > $OUT/${tag}_${label}_$c.log 2>&1
   done
   echo "== $label: pmc clock + matrix-pipe busy"
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/${tag}_${label}_busy -- python3 $ROOT/bench.py "$@" --steps 1 --warmup 0 > $OUT/${tag}_${label}_busy.log 2>&1
-  python3 $ROOT/tools/pmc_report.py $OUT/${tag}_${label}_FETCH_SIZE $OUT/${tag}_${label}_WRITE_SIZE $OUT/${tag}_${label}_busy $OUT/$out 32 480 640 $mode $es | tee $OUT/${tag}_${label}_pmc.txt
+  python3 $ROOT/tools/pmc_report.py $OUT/${tag}_${label}_FETCH_SIZE $OUT/${tag}_${label}_WRITE_SIZE $OUT/${tag}_${label}_busy $OUT/$out $shape $mode $es | tee $OUT/${tag}_${label}_pmc.txt
   find $OUT/${tag}_${label}_FETCH_SIZE $OUT/${tag}_${label}_WRITE_SIZE $OUT/${tag}_${label}_busy -name "*.csv" -size +8M -delete
 }
 trace() { # trace <label> <stats.csv name> <bench args...>
@@ -43,8 +45,13 @@ trace bf16fwd ${tag}_bf16_fwd_b32_480x640_kernel_stats.csv --dtype bf16 --no-cpu
 pmc3 bf16fwd ${tag}_bf16_fwd_b32_480x640_pmc.json fwd 2 --dtype bf16 --no-cpu-baseline --no-fwd-bwd
 trace bf16train ${tag}_bf16_train_b32_480x640_kernel_stats.csv --mode train --dtype bf16 --no-cpu-baseline --steps 3 --warmup 1
 pmc3 bf16train ${tag}_bf16_train_b32_480x640_pmc.json train 2 --mode train --dtype bf16 --no-cpu-baseline
+# round 6: one PMC pass each for BASELINE configs[3] (x8, b16, 960 x 1280, fp32) and configs[4] (x16, b8, 1920 x 2560, bf16), so
+# that their bench lines carry roofline.traffic too
+PMC_SHAPE="16 960 1280" pmc3 x8fwd ${tag}_x8_fwd_b16_960x1280_pmc.json fwd 4 --scale 8 --batch 16 --height 960 --width 1280 --no-cpu-baseline --no-fwd-bwd
+PMC_SHAPE="8 1920 2560" pmc3 x16fwd ${tag}_x16_bf16_fwd_b8_1920x2560_pmc.json fwd 2 --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 --no-cpu-baseline --no-fwd-bwd
 # the lines below read roofline.traffic from profiles/: give them the tables of THIS library (traffic_from_hash == lib_source_hash)
-cp $OUT/${tag}_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_train_b32_480x640_pmc.json $ROOT/profiles/
+cp $OUT/${tag}_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_train_b32_480x640_pmc.json \
+   $OUT/${tag}_x8_fwd_b16_960x1280_pmc.json $OUT/${tag}_x16_bf16_fwd_b8_1920x2560_pmc.json $ROOT/profiles/
 fi
 run bench_default --steps 5 --warmup 2
 run bench_bf16 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
