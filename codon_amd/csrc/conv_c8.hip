@@ -93,11 +93,8 @@ template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = 4; };
 // The body takes its parameter block by reference and the (XCD-remapped) tile it starts on as an argument, so that the
 // same code serves the one-conv launch and the PAIR launch (conv_c8_pair_kernel below: two convs of one shape, e.g. the
 // depth and the colour stream of a block, as one grid).
-// PS (round 6): pixel rows per wave when not the default of ConvC8Pseg -- 1 = a 4 x 32 tile for launches of a few rounds of
-// workgroups (one image per call): twice the workgroups of half the work each, so the last round is shorter.  Per-pixel
-// arithmetic and its order do not depend on the tile; the fused statistics are per 4-ROW STRIP whatever the tile (below).
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
-          bool RESW = false, int PS = 0>
+          bool RESW = false>
 __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int tile0) {
   static_assert(!PERSIST || (!FUSE && !GATE && C8_DMA), "the tile loop exists for the plain LDS-DMA convs");
   static_assert(!RESW || PERSIST, "a resident filter pays only over many tiles");
@@ -105,7 +102,7 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
   typedef const volatile __attribute__((address_space(3))) u32x4* lds_rd;
   typedef volatile __attribute__((address_space(3))) u32x4* lds_w128;
   constexpr int PAD = KS / 2;
-  constexpr int PSEG = PS ? PS : ConvC8Pseg<KS, COUT>::value;
+  constexpr int PSEG = ConvC8Pseg<KS, COUT>::value;
   constexpr int NT = 64 * NW;
   constexpr int TW = 32, TH = NW * PSEG;
   constexpr int XR = TH + KS - 1, XQ = TW + KS - 1;
@@ -486,40 +483,12 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
           for (int i = 0; i < PSEG; ++i) d[t2][i] = E::mfma(a, *reinterpret_cast<const vec8*>(&pk[i][t][g]), d[t2][i]);
         }
     }
-    // Statistics (p.st_pool != nullptr).  Per pixel { max, sum } over the launch's 64 channels; per channel { sum, max } over
-    // 4-ROW STRIPS of 32 pixels -- strip (y / 4, tile column) -- built so that every tiling gives the same bits (round 6): a
-    // row's 32 pixels of a channel are summed in lane order (the transposed read below), a strip is ((R0 + R1) + R2) + R3 over
-    // its rows, maxima are order-free; cac_tail / cac_fold then add the strips in index order.  An 8 x 32 tile holds two
-    // strips, a 4 x 32 tile one: an image's gates do not depend on the tile its launch took, i.e. not on its batch.
-    constexpr int TROWS = NW * PSEG, NSTRIP = TROWS / 4;
-    static_assert(TROWS % 4 == 0 && (PSEG == 1 || PSEG == 2 || PSEG == 4), "strips are 4 rows: a wave's rows lie in one strip");
-    float pmx[PSEG], psm[PSEG], csum[32], cmax[32], rs_row[PSEG];
+    float pmx[PSEG], psm[PSEG], csum[32], cmax[32];
     bool valid[PSEG];
-    float* const tr = reinterpret_cast<float*>(lds) + wave * (64 * 36);
-    float* const red = reinterpret_cast<float*>(lds) + NW * (64 * 36);      // [TROWS + NW][64]: row sums, then wave maxima
-    static_assert((NW * 64 * 36 + (TROWS + NW) * 64) * 4 <= (2 * XSP + 2 * WSP) * 16, "statistics scratch fits the stage buffers");
-    // per channel: transpose through LDS (free after the last stage's barrier): lane L writes its 32 values as a row of 36
-    // floats (144-byte pitch: conflict-free ds_write_b128), then lane (c, half) folds column c over the 32 rows of its half
-    auto transposed = [&](const float (&src)[32], auto maxc) {
-      constexpr bool MX = decltype(maxc)::value;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        *reinterpret_cast<float4*>(tr + lane * 36 + 4 * k) = make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
-      __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's own writes have landed
-      __builtin_amdgcn_wave_barrier();
-      float a = MX ? -INFINITY : 0.f;
+    for (int i = 0; i < PSEG; ++i) { pmx[i] = -INFINITY; psm[i] = 0.f; valid[i] = vo[i] != C8_OOB; }
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const float v = tr[(half * 32 + r) * 36 + l31];
-        a = MX ? fmaxf(a, v) : a + v;
-      }
-      __builtin_amdgcn_wave_barrier();
-      return a;
-    };
-#pragma unroll
-    for (int i = 0; i < PSEG; ++i) { pmx[i] = -INFINITY; psm[i] = 0.f; valid[i] = vo[i] != C8_OOB; rs_row[i] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 32; ++k) cmax[k] = -INFINITY;
+    for (int k = 0; k < 32; ++k) { csum[k] = 0.f; cmax[k] = -INFINITY; }
 #pragma unroll
     for (int i = 0; i < PSEG; ++i) {
       u32x4 rv[2][2];
@@ -529,8 +498,6 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
 #pragma unroll
           for (int g = 0; g < 2; ++g) rv[t2][g] = c8_ld(rrsrc, vo[i], cplane(t2, g));
       }
-#pragma unroll
-      for (int k = 0; k < 32; ++k) csum[k] = 0.f;
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -553,12 +520,11 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
             for (int j = 0; j < 8; ++j) {
               pmx[i] = fmaxf(pmx[i], r8[j]);
               psm[i] += r8[j];
-              csum[t2 * 16 + g * 8 + j] = valid[i] ? r8[j] : 0.f;
+              csum[t2 * 16 + g * 8 + j] += valid[i] ? r8[j] : 0.f;
               cmax[t2 * 16 + g * 8 + j] = valid[i] ? fmaxf(cmax[t2 * 16 + g * 8 + j], r8[j]) : cmax[t2 * 16 + g * 8 + j];
             }
           }
         }
-      if (p.st_pool) rs_row[i] = transposed(csum, std::false_type{});      // this row's 32-pixel sums, lane (c, half)
     }
     if (p.st_pool) {
       // per pixel: this lane holds 32 of the pixel's 64 channels, lane + 32 the other 32
@@ -572,25 +538,45 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
           p.st_pool[(long)b_e * 2 * HWl + HWl + q] = s2;
         }
       }
-      const float rm = transposed(cmax, std::true_type{});
+      // per channel: transpose through LDS (free after the last stage's barrier): lane L writes its 32 values as a
+      // row of 36 floats (144-byte pitch: conflict-free ds_write_b128), then lane (c, half) sums column c over the 32
+      // rows of its half; sums first, maxima second, through the same region
+      float* const tr = reinterpret_cast<float*>(lds) + wave * (64 * 36);
+      float* const red = reinterpret_cast<float*>(lds) + NW * (64 * 36);      // [2][NW][64]
+      static_assert((NW * 64 * 36 + 2 * NW * 64) * 4 <= (2 * XSP + 2 * WSP) * 16, "statistics scratch fits the stage buffers");
+      float rs = 0.f, rm = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < PSEG; ++i) red[(wave * PSEG + i) * 64 + lane] = rs_row[i];
-      red[(TROWS + wave) * 64 + lane] = rm;
-      __syncthreads();
-      if (wave < NSTRIP) {                          // wave s finishes strip s of the tile: rows 4s .. 4s + 3, in row order
-        const int sy = (ty0_e >> 2) + wave, nsy = (H + 3) >> 2;
-        if (sy < nsy) {                             // (an 8 x 32 tile over the image's last 1..4 rows has one strip only)
-          const float s = ((red[(4 * wave + 0) * 64 + lane] + red[(4 * wave + 1) * 64 + lane]) + red[(4 * wave + 2) * 64 + lane]) +
-                          red[(4 * wave + 3) * 64 + lane];
-          constexpr int WPS = 4 / PSEG;             // waves per strip
-          float m = red[(TROWS + wave * WPS) * 64 + lane];
+      for (int pass = 0; pass < 2; ++pass) {
+        const float* src = pass ? cmax : csum;
 #pragma unroll
-          for (int w = 1; w < WPS; ++w) m = fmaxf(m, red[(TROWS + wave * WPS + w) * 64 + lane]);
-          const int ch = (l31 >> 4) * 32 + ((l31 >> 3) & 1) * 16 + 8 * half + (l31 & 7);   // value index -> channel (swap23 layout)
-          float2* out = reinterpret_cast<float2*>(p.st_part) +
-                        ((((long)b_e * nsy + sy) * p.tiles_x + tx_e) * 128 + p.st_choff + ch);
-          *out = make_float2(s, m);
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<float4*>(tr + lane * 36 + 4 * k) = make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's own writes have landed
+        __builtin_amdgcn_wave_barrier();
+        float a = pass ? -INFINITY : 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const float v = tr[(half * 32 + r) * 36 + l31];
+          a = pass ? fmaxf(a, v) : a + v;
         }
+        if (pass) rm = a; else rs = a;
+        __builtin_amdgcn_wave_barrier();
+      }
+      red[(0 * NW + wave) * 64 + lane] = rs;
+      red[(1 * NW + wave) * 64 + lane] = rm;
+      __syncthreads();
+      if (wave == 0) {
+        float s = red[lane], m = red[NW * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {            // fixed order: deterministic
+          s += red[w * 64 + lane];
+          m = fmaxf(m, red[(NW + w) * 64 + lane]);
+        }
+        const int ch = (l31 >> 4) * 32 + ((l31 >> 3) & 1) * 16 + 8 * half + (l31 & 7);   // value index -> channel (swap23 layout)
+        const long tile = (long)ty_e * p.tiles_x + tx_e;
+        float2* out = reinterpret_cast<float2*>(p.st_part) +
+                      (((long)b_e * p.tiles_x * p.tiles_y + tile) * 128 + p.st_choff + ch);
+        *out = make_float2(s, m);
       }
     }
     return;
@@ -690,9 +676,9 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
 }
 
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
-          bool RESW = false, int PS = 0>
+          bool RESW = false>
 __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void conv_c8_kernel(const ConvC8Params p) {
-  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, PERSIST, RESW, PS>(p, (int)xcd_remap(blockIdx.x, PERSIST ? gridDim.x : (unsigned)p.nblk));
+  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, PERSIST, RESW>(p, (int)xcd_remap(blockIdx.x, PERSIST ? gridDim.x : (unsigned)p.nblk));
 }
 
 // Two convs of ONE shape and kernel variant as one grid of 2 * nblk workgroups (round 5).  The depth and the colour stream of
@@ -705,12 +691,12 @@ struct ConvC8Pair {
   ConvC8Params a, b;
 };
 static_assert(sizeof(ConvC8Pair) <= CODON_KERNARG_LIMIT, "two parameter blocks passed by value as one kernel argument");
-template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, int PS = 0>
+template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_c8_pair_kernel(const ConvC8Pair pp) {
   const int nblk = pp.a.nblk;                                       // == pp.b.nblk (checked on the host)
   const int v = (int)xcd_remap(blockIdx.x, 2u * (unsigned)nblk);
   const bool second = v >= nblk;                                    // workgroup-uniform
-  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, false, false, PS>(second ? pp.b : pp.a, second ? v - nblk : v);
+  conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, false, false>(second ? pp.b : pp.a, second ? v - nblk : v);
 }
 
 // ---- 1x1 convolution (stand-alone confuse* and their dgrad): HBM-bound ---------------------------------------------
@@ -956,35 +942,20 @@ static int c8_resident_blocks(K kernel, int threads) {
 // path wants many short workgroups).  (The tile loop with STAGED weights, for the plain 3x3 and 5x5 64->64 convs, was
 // measured as a loss and is gone: tools/probes/conv_c8_persist_staged_experiment.patch, profiles/HISTORY.md.)
 constexpr int C8_RESIDENT_MIN_TILES = 8;
-template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE, int PS = 0>
+template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
 static int launch_single_c8(const void* pv, hipStream_t stream) {
   const ConvC8Params& p = *static_cast<const ConvC8Params*>(pv);
-  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, false, false, PS>), dim3((unsigned)p.nblk), dim3(64 * NW), 0,
-                     stream, p);
+  hipLaunchKernelGGL((conv_c8_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3((unsigned)p.nblk), dim3(64 * NW), 0, stream, p);
   return check_launch("conv_c8_kernel");
 }
-template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE, int PS = 0>
+template <class E, int KS, int CIN, int COUT, bool FUSE, int NW, bool GATE>
 static int launch_pair_c8(const void* av, const void* bv, hipStream_t stream) {
   ConvC8Pair pp;
   pp.a = *static_cast<const ConvC8Params*>(av);
   pp.b = *static_cast<const ConvC8Params*>(bv);
-  hipLaunchKernelGGL((conv_c8_pair_kernel<E, KS, CIN, COUT, FUSE, NW, GATE, PS>), dim3(2u * (unsigned)pp.a.nblk), dim3(64 * NW), 0,
+  hipLaunchKernelGGL((conv_c8_pair_kernel<E, KS, CIN, COUT, FUSE, NW, GATE>), dim3(2u * (unsigned)pp.a.nblk), dim3(64 * NW), 0,
                      stream, pp);
   return check_launch("conv_c8_pair_kernel");
-}
-
-// 4 x 32 TILES FOR LAUNCHES OF A FEW ROUNDS -- measured in round 6 and NOT taken (one image per call,
-// /root/reference/CODON_X4/test.py:116-125).  A CU works through its workgroups at a fixed rate whether one or two are resident
-// (tools/probes/c8_rounds_sweep.py: the chained conv costs 10 + 36 us per started 256 tiles of 8 x 32), so a launch takes
-// ceil(tiles / 256) tile times: one 370 x 463 image as a PAIR is 1 410 tiles = 5.5 -> 6, and on 4 x 32 tiles it would be
-// 2 790 = 10.9 -> 11 half tiles.  But a 4 x 32 tile costs 0.62 of an 8 x 32 one, not 0.5 (tools/probes/c8_tile_ab.py, ten image
-// heights: pair at 370 rows 219.7 -> 248.3 us, lone 113.3 -> 131.2; slower at every height): each workgroup stages the same
-// 20 KB of weights per stage for half the MFMAs, 2 x 24.6 KB per 640 cycles and CU = 77 B/clk against the 64 B/clk a CU draws
-// from L2 (8 x 32: 42 B/clk), and an A fragment serves one pixel row instead of two.  The PS = 1 kernels stay for the
-// tiling-invariance tests (CODON_C8_CHAIN_TILE=4 forces them); the fused statistics are per 4-row strip either way.
-static bool c8_chain_half_tiles(const codon_conv_desc*) {
-  const char* const fe = getenv("CODON_C8_CHAIN_TILE");          // tests / A/B: "4" forces the 4 x 32 tile (read per call)
-  return fe && atoi(fe) == 4;
 }
 
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
@@ -992,18 +963,6 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
   constexpr int TH = NW * ConvC8Pseg<KS, COUT>::value;
   p.tiles_x = (d->width + 31) / 32;
-  if constexpr (FUSE && KS == 5 && COUT == 128) {
-    if (c8_chain_half_tiles(d)) {                    // 4 x 32 tiles (see above)
-      p.tiles_y = (d->height + NW - 1) / NW;
-      const long nb4 = (long)p.tiles_x * p.tiles_y * d->batch;
-      CODON_REQUIRE(nb4 < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nb4);
-      p.nblk = (int)nb4;
-      if (const int held = pair_hold(p, &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE, 1>,
-                                     &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE, 1>, stream))
-        return held < 0 ? held : CODON_OK;
-      return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE, 1>(&p, stream);
-    }
-  }
   p.tiles_y = (d->height + TH - 1) / TH;
   const long nblk = (long)p.tiles_x * p.tiles_y * d->batch;
   CODON_REQUIRE(nblk < (1L << 31), CODON_ERR_UNSUPPORTED, "conv2d_fwd: grid too large (%ld blocks)", nblk);
@@ -1148,9 +1107,16 @@ int conv2d_gated_fwd_16(const codon_conv_desc* d, const void* pre, const codon_t
   return d->dtype == CODON_F16 ? conv2d_gated_c8<C8F16>(p, d, stream) : conv2d_gated_c8<C8Bf16>(p, d, stream);
 }
 
-// rows of the fused-statistics partials: 4-row strips of 32 pixels (whatever tile the chained conv ran on)
+// tiles of the fused-statistics partials: the conv5x5 128->128 kernel's 8 x 32 (NW * PSEG rows) pixel tiles.
+// (Round 6 measured the alternative the round-5 review asked for -- 4 x 32 tiles for launches of a few rounds of workgroups,
+// with the statistics per 4-row strip so that both tilings give the same bits: a 4 x 32 tile costs 0.62 of an 8 x 32 one,
+// not 0.5 -- its weight staging is L2-bound, 77 B/clk per CU against the 64 a CU draws -- so it was slower at every image
+// height (one 370 x 463 image as a pair 219.7 -> 248.3 us), and the strips doubled the one-launch gate's fold (20 -> 31 us
+// per block).  Every 16-bit launch keeps the 8 x 32 tile at any batch, so per-tile partials are batch-invariant as they are.
+// tools/probes/c8_4x32_tiles_strip_statistics_experiment.patch, tools/probes/c8_tile_ab.py, profiles/HISTORY.md.)
 int cac_fused_tiles(int H, int W) {
-  return ((W + 31) / 32) * ((H + 3) / 4);
+  constexpr int TH = ConvC8Nw<5, 128>::value * ConvC8Pseg<5, 128>::value;
+  return ((W + 31) / 32) * ((H + TH - 1) / TH);
 }
 
 }  // namespace codon

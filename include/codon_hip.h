@@ -130,11 +130,9 @@ int codon_conv_chain1x1_fwd(const codon_conv_desc* d, const void* x, const void*
  * epilogue (the values as stored, i.e. 16-bit tensors: rounded to 16 bits), instead of a separate pass over the tensor
  * (codon_cac_stats_fwd; F.avg_pool2d / F.max_pool2d / ChannelPool, /root/reference/CODON_X4/CAC_module.py:43,47,81):
  *   stats_pool     (B,2,H,W) fp32 : per pixel { max, SUM } over THIS stream's 64 channels
- *   stats_partials (B, codon_cac_fused_tiles(H,W), 128, 2) fp32 : per 4-ROW STRIP of 32 pixels (strip (y / 4, x / 32); round 5:
- *                  per 8 x 32 conv tile), per channel { sum, max } written at channels [stats_choff, stats_choff + 64):
- *                  0 = colour stream (Fcat channels 0..63), 64 = depth.  A strip is summed in one fixed order whatever tile
- *                  (8 x 32 or, for launches of a few rounds of workgroups, 4 x 32) the launch ran on, and the strips are folded
- *                  in index order: the statistics do not depend on the tiling, i.e. not on the batch an image arrives in.
+ *   stats_partials (B, codon_cac_fused_tiles(H,W), 128, 2) fp32 : per 8 x 32 conv tile, per channel { sum, max } written at
+ *                  channels [stats_choff, stats_choff + 64): 0 = colour stream (Fcat channels 0..63), 64 = depth.  Every
+ *                  16-bit launch runs on 8 x 32 tiles whatever the batch, so the partials of an image do not depend on it.
  * Two launches (one per stream) fill one partials buffer.  Then
  *   codon_cac_fused_finish   : folds the tiles into CODON_CAC_FOLDS rows in fixed order (`folded`: (B, CODON_CAC_FOLDS, 128, 2)
  *                              scratch) and combines the two stream maps into pooled (B,2,H,W) = { max, mean over 128 }

@@ -1,4 +1,4 @@
-"""Round 6: the 16-bit chained conv on 8 x 32 against 4 x 32 tiles (CODON_C8_CHAIN_TILE), alone and as a pair, over image
+"""Round 6 (needs tools/probes/c8_4x32_tiles_strip_statistics_experiment.patch applied): the 16-bit chained conv on 8 x 32 against 4 x 32 tiles (CODON_C8_CHAIN_TILE), alone and as a pair, over image
 heights at W = 463, and the one-image forward with the rule on / forced to 8.  c8_tile_ab.py [fp16|bf16]"""
 import os
 import sys
