@@ -38,21 +38,32 @@ trace() { # trace <label> <stats.csv name> <bench args...>
 }
 
 # LINES_ONLY=1: only the bench lines (the PMC tables of this library are already in profiles/)
+# PART=a|b|c (round 6: a gpurun call is at most 20 minutes): a = traces + PMC of the three 32 x 480 x 640 workloads, b = PMC of
+# configs[3] / [4], c = the bench lines + the one-image timelines.  Copy gpurun_out/<tag>_*_pmc.json into profiles/ between
+# the calls (every call starts on a fresh box); without PART everything runs in one go.
+# (--no-strong-shards: the default line's b16 / b8 / b4 shard timings launch the same kernels on smaller batches and would
+# be averaged into the per-kernel rows)
+part=${PART:-abc}
 if [ -z "$LINES_ONLY" ]; then
-trace default ${tag}_default_bench_kernel_stats.csv --steps 3 --warmup 1 --no-cpu-baseline --no-script-pattern
-pmc3 fwd ${tag}_fwd_b32_480x640_pmc.json fwd 4 --no-cpu-baseline --no-fwd-bwd --no-script-pattern
+if [[ $part == *a* ]]; then
+trace default ${tag}_default_bench_kernel_stats.csv --steps 3 --warmup 1 --no-cpu-baseline --no-script-pattern --no-strong-shards
+pmc3 fwd ${tag}_fwd_b32_480x640_pmc.json fwd 4 --no-cpu-baseline --no-fwd-bwd --no-script-pattern --no-strong-shards
 trace bf16fwd ${tag}_bf16_fwd_b32_480x640_kernel_stats.csv --dtype bf16 --no-cpu-baseline --no-fwd-bwd --steps 3 --warmup 1
 pmc3 bf16fwd ${tag}_bf16_fwd_b32_480x640_pmc.json fwd 2 --dtype bf16 --no-cpu-baseline --no-fwd-bwd
 trace bf16train ${tag}_bf16_train_b32_480x640_kernel_stats.csv --mode train --dtype bf16 --no-cpu-baseline --steps 3 --warmup 1
 pmc3 bf16train ${tag}_bf16_train_b32_480x640_pmc.json train 2 --mode train --dtype bf16 --no-cpu-baseline
+fi
+if [[ $part == *b* ]]; then
 # round 6: one PMC pass each for BASELINE configs[3] (x8, b16, 960 x 1280, fp32) and configs[4] (x16, b8, 1920 x 2560, bf16), so
 # that their bench lines carry roofline.traffic too
 PMC_SHAPE="16 960 1280" pmc3 x8fwd ${tag}_x8_fwd_b16_960x1280_pmc.json fwd 4 --scale 8 --batch 16 --height 960 --width 1280 --no-cpu-baseline --no-fwd-bwd
 PMC_SHAPE="8 1920 2560" pmc3 x16fwd ${tag}_x16_bf16_fwd_b8_1920x2560_pmc.json fwd 2 --scale 16 --dtype bf16 --batch 8 --height 1920 --width 2560 --no-cpu-baseline --no-fwd-bwd
-# the lines below read roofline.traffic from profiles/: give them the tables of THIS library (traffic_from_hash == lib_source_hash)
-cp $OUT/${tag}_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_train_b32_480x640_pmc.json \
-   $OUT/${tag}_x8_fwd_b16_960x1280_pmc.json $OUT/${tag}_x16_bf16_fwd_b8_1920x2560_pmc.json $ROOT/profiles/
 fi
+# the lines below read roofline.traffic from profiles/: give them the tables of THIS library (traffic_from_hash == lib_source_hash)
+for f in $OUT/${tag}_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_fwd_b32_480x640_pmc.json $OUT/${tag}_bf16_train_b32_480x640_pmc.json \
+   $OUT/${tag}_x8_fwd_b16_960x1280_pmc.json $OUT/${tag}_x16_bf16_fwd_b8_1920x2560_pmc.json; do test -f $f && cp $f $ROOT/profiles/; done
+fi
+[[ $part == *c* ]] || { echo "done (part $part)"; exit 0; }
 run bench_default --steps 5 --warmup 2
 run bench_bf16 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
 run train_bf16 --mode train --dtype bf16 --steps 10 --warmup 2
