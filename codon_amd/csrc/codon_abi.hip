@@ -561,6 +561,16 @@ int codon_conv_pair_end(codon_stream_t stream) {
     const int st = a.pair(a.blob, b.blob, (hipStream_t)stream);
     return st == CODON_OK ? 1 : st;
   }
+  // a conv5x5 64->64 and the conv3x3 64->64 of the same family (mix53): one grid of both kinds of workgroup
+  if (n == 2 && a.stream == (hipStream_t)stream && b.stream == (hipStream_t)stream && a.mix_kind && b.mix_kind &&
+      (long)a.nblk + b.nblk < (1L << 31)) {
+    const PairCall* five = (a.mix_kind & 1) ? &a : &b;
+    const PairCall* three = (a.mix_kind & 1) ? &b : &a;
+    if ((five->mix_kind & 1) && three->mix_kind == five->mix_kind + 1 && five->mix) {
+      const int st = five->mix(five->blob, three->blob, (hipStream_t)stream);
+      return st == CODON_OK ? 1 : st;
+    }
+  }
   for (int k = 0; k < n; ++k) {          // one by one, each on the stream its call named
     const int st = g_pair.call[k].single(g_pair.call[k].blob, g_pair.call[k].stream);
     if (st != CODON_OK) return st;

@@ -93,9 +93,15 @@ template <int KS, int COUT> struct ConvC8Nw { static constexpr int value = 4; };
 // The body takes its parameter block by reference and the (XCD-remapped) tile it starts on as an argument, so that the
 // same code serves the one-conv launch and the PAIR launch (conv_c8_pair_kernel below: two convs of one shape, e.g. the
 // depth and the colour stream of a block, as one grid).
+// LDS of one workgroup of the staged (non-resident) kernels, in 16-byte elements (the body's own arithmetic, restated for
+// kernels that hold the arena themselves)
+template <int KS, int CIN, int COUT, int NW> constexpr int conv_c8_lds_vecs();
+
+// EXTLDS (round 6): the staging arena is the CALLER's (mix53 below runs two different bodies in one grid on one arena of the
+// larger size); every other instantiation declares its own, as before.
 template <class E, int KS, int CIN, int COUT, bool FUSE = false, int NW = 4, bool GATE = false, bool PERSIST = false,
-          bool RESW = false>
-__device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int tile0) {
+          bool RESW = false, bool EXTLDS = false>
+__device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int tile0, uint4* ext_lds = nullptr) {
   static_assert(!PERSIST || (!FUSE && !GATE && C8_DMA), "the tile loop exists for the plain LDS-DMA convs");
   static_assert(!RESW || PERSIST, "a resident filter pays only over many tiles");
   typedef typename E::vec8 vec8;
@@ -120,7 +126,9 @@ __device__ __forceinline__ void conv_c8_body(const ConvC8Params& p, const int ti
   static_assert((XSP + (KS + PSEG) * XQ) * 16 < 65536 && 2 * WSP * 16 < 65536 && (!RESW || 2 * KS * WS * 16 < 65536),
                 "LDS immediates are 16 bits per region");
 
-  __shared__ uint4 lds[2 * XSP + WTOT];
+  static_assert(RESW || 2 * XSP + WTOT == conv_c8_lds_vecs<KS, CIN, COUT, NW>(), "conv_c8_lds_vecs restates this");
+  __shared__ uint4 lds_own[EXTLDS ? 1 : 2 * XSP + WTOT];
+  uint4* const lds = EXTLDS ? ext_lds : lds_own;
   uint4* const xs0 = lds;
   uint4* const ws0 = lds + 2 * XSP;
 
@@ -699,6 +707,29 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_c8_pair_kernel(const ConvC8Pa
   conv_c8_body<E, KS, CIN, COUT, FUSE, NW, GATE, false, false>(second ? pp.b : pp.a, second ? v - nblk : v);
 }
 
+template <int KS, int CIN, int COUT, int NW> constexpr int conv_c8_lds_vecs() {
+  constexpr int PSEG = ConvC8Pseg<KS, COUT>::value, NT = 64 * NW, TH = NW * PSEG, XR = TH + KS - 1, XQ = 32 + KS - 1;
+  constexpr int XS = 2 * XR * XQ, WS = KS * 2 * COUT, XE = (XS + NT - 1) / NT, WE = (WS + NT - 1) / NT;
+  return 2 * XE * NT + 2 * WE * NT;
+}
+
+// mix53 (round 6): conv8 (5x5 64->64, 16 x 32 tiles) and conv9 (3x3 64->64, 8 x 32 tiles) of the fusion trunk read the same
+// tensor and are independent (/root/reference/CODON_X4/CODON_x4.py:123-124); at one image per call they are two launches of
+// 2 and 3 rounds of workgroups (38 + 16 us at 370 x 463).  Held in one pair bracket they leave as ONE grid: workgroups
+// [0, nA) run the 5x5 body on its tiles, [nA, nA + nB) the 3x3 body on its own, on one LDS arena of the larger size.  No XCD
+// remap: every XCD takes every 8th workgroup of BOTH kinds; the expensive tiles are dispatched first, the cheap ones fill
+// the tail.  Same body code per tile: same bits as the separate launches.
+template <class E>
+__global__ __launch_bounds__(256, 2) void conv_c8_mix53_kernel(const ConvC8Pair pp) {
+  constexpr int LA = conv_c8_lds_vecs<5, 64, 64, 4>(), LB = conv_c8_lds_vecs<3, 64, 64, 4>();
+  __shared__ uint4 arena[LA > LB ? LA : LB];
+  const int nA = pp.a.nblk;
+  if ((int)blockIdx.x < nA)                                          // workgroup-uniform
+    conv_c8_body<E, 5, 64, 64, false, 4, false, false, false, true>(pp.a, (int)blockIdx.x, arena);
+  else
+    conv_c8_body<E, 3, 64, 64, false, 4, false, false, false, true>(pp.b, (int)blockIdx.x - nA, arena);
+}
+
 // ---- 1x1 convolution (stand-alone confuse* and their dgrad): HBM-bound ---------------------------------------------
 // Y[co][pix] = sum_ci W[co][ci] X[ci][pix]: a plain GEMM over the flattened pixels of one image, no halo, no LDS.  A
 // wave owns 64 consecutive pixels (two 32-pixel MFMA column tiles) and all COUT rows.  B fragment of lane (pixel,
@@ -958,6 +989,15 @@ static int launch_pair_c8(const void* av, const void* bv, hipStream_t stream) {
   return check_launch("conv_c8_pair_kernel");
 }
 
+template <class E>
+static int launch_mix53_c8(const void* five, const void* three, hipStream_t stream) {
+  ConvC8Pair pp;
+  pp.a = *static_cast<const ConvC8Params*>(five);
+  pp.b = *static_cast<const ConvC8Params*>(three);
+  hipLaunchKernelGGL((conv_c8_mix53_kernel<E>), dim3((unsigned)pp.a.nblk + (unsigned)pp.b.nblk), dim3(256), 0, stream, pp);
+  return check_launch("conv_c8_mix53_kernel");
+}
+
 template <class E, int KS, int CIN, int COUT, bool FUSE, bool GATE = false>
 static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t stream) {
   constexpr int NW = ConvC8Nw<KS, COUT>::value;
@@ -985,8 +1025,13 @@ static int launch_conv_c8(ConvC8Params& p, const codon_conv_desc* d, hipStream_t
   }
   // inside codon_conv_pair_begin / _end the launch is held back: pair_end issues two held launches of the same kernel variant
   // on the same grid as ONE, anything else one by one in the order they came
+  // (the plain 64 -> 64 convs can also leave as a mix53 grid with their sibling of the other filter size)
+  constexpr bool MIXABLE = !FUSE && !GATE && CIN == 64 && COUT == 64 && NW == 4 && (KS == 5 || KS == 3);
+  constexpr int k5 = std::is_same<E, C8F16>::value ? MIX_C8F16_5 : MIX_C8BF16_5;
+  constexpr int kind = !MIXABLE ? MIX_NONE : KS == 5 ? k5 : k5 + 1;
   if (const int held = pair_hold(p, &launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>,
-                                 &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>, stream))
+                                 &launch_pair_c8<E, KS, CIN, COUT, FUSE, NW, GATE>, stream, kind,
+                                 (MIXABLE && KS == 5) ? &launch_mix53_c8<E> : nullptr))
     return held < 0 ? held : CODON_OK;
   return launch_single_c8<E, KS, CIN, COUT, FUSE, NW, GATE>(&p, stream);
 }

@@ -122,9 +122,20 @@ enum { RES_NONE = 0, RES_ADD = 1, RES_MASK = 2 };
 // whatever the tile shape (8 x 32, 4 x 32, 2 x 32 cout-split), and are summed by one fixed DPP tree; the strips are folded in
 // index order afterwards (cac_tail_kernel): the statistics -- hence the gates, hence the image -- do not depend on the tiling,
 // i.e. on the batch an image arrives in.  One 128 x 128 image: five 22-us statistics passes per forward gone.
+// LDS of one workgroup, in floats (the body's own arithmetic, restated for kernels that hold the arena themselves)
+template <int KS, int CIN, int COUT, int PSEG, int NW, bool CSPLIT>
+constexpr int conv_f32_lds_floats() {
+  constexpr int TW = 32, TH = (CSPLIT ? NW / 2 : NW) * PSEG, XR = TH + KS - 1, XQ = TW + KS - 1;
+  constexpr int CK = ConvCfg<KS, CIN>::CK, XS = CK * XR * XQ, WS = CK * KS * COUT, NT = NW * 64;
+  constexpr int W4 = WS / 4, WE = (W4 + NT - 1) / NT, XSP = (XS + 3) & ~3, WSP = WE * NT * 4;
+  return 2 * XSP + 2 * WSP;
+}
+
+// EXTLDS (round 6): the staging arena is the CALLER's (a kernel that runs two different bodies in one grid, mix53 below,
+// declares one arena of the larger size); every other instantiation declares its own, as before.
 template <int KS, int CIN, int COUT, int PSEG, bool FUSE = false, bool GATE = false, int NW = 4, bool CSPLIT = false,
-          bool ST = false>
-__device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid) {
+          bool ST = false, bool EXTLDS = false>
+__device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned bid, float* ext_lds = nullptr) {
   static_assert(!CSPLIT || (PSEG == 1 && NW == 4 && COUT % 64 == 0), "the cout-split form is a small-grid conv");
   static_assert(!ST || FUSE, "statistics come out of the chained 1x1's epilogue");
   constexpr int NT = NW * 64;
@@ -142,7 +153,9 @@ __device__ __forceinline__ void conv_mfma_f32_body(const ConvParams& p, unsigned
   constexpr int XSP = (XS + 3) & ~3, WSP = WE * NT * 4;   // the weight buffer is padded to whole rounds: no store predicates
   static_assert(WS % 4 == 0, "weight stage must be whole float4s");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * XSP + 2 * WSP];
+  static_assert(2 * XSP + 2 * WSP == conv_f32_lds_floats<KS, CIN, COUT, PSEG, NW, CSPLIT>(), "conv_f32_lds_floats restates this");
+  __shared__ __attribute__((aligned(16))) float lds_own[EXTLDS ? 4 : 2 * XSP + 2 * WSP];
+  float* const lds = EXTLDS ? ext_lds : lds_own;
   float* const xs0 = lds;
   float* const ws0 = lds + 2 * XSP;
 
@@ -630,6 +643,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_f32_pair_kernel(const Co
   conv_mfma_f32_body<KS, CIN, COUT, PSEG, FUSE, GATE, NW, CSPLIT, ST>(second ? pp.b : pp.a, second ? v - nblk : v);
 }
 
+// mix53 (round 6): conv8 (5x5 64->64) and conv9 (3x3 64->64) of the fusion trunk read the same tensor and are independent
+// (/root/reference/CODON_X4/CODON_x4.py:123-124); at one image per call each is a launch of a few rounds with its own ramp and
+// drain (35 + 17 us at 1 x 128 x 128).  Held in one pair bracket they leave as ONE grid: workgroups [0, nA) run the 5x5 body on
+// its tiles, [nA, nA + nB) the 3x3 body on its own -- the small-grid cout-split forms of both, one LDS arena of the larger size.
+// No XCD remap: consecutive workgroups go to consecutive XCDs, so every XCD takes every 8th workgroup of BOTH kinds (a
+// contiguous split would give five XCDs the expensive tiles and three the cheap ones), the 5x5 tiles are dispatched first
+// and the 3x3 ones fill the tail.  Same body code per tile: same bits as the separate launches.
+__global__ __launch_bounds__(256, 2) void conv_mfma_f32_mix53_kernel(const ConvPair pp) {
+  constexpr int LA = conv_f32_lds_floats<5, 64, 64, 1, 4, true>(), LB = conv_f32_lds_floats<3, 64, 64, 1, 4, true>();
+  __shared__ __attribute__((aligned(16))) float arena[LA > LB ? LA : LB];
+  const unsigned nA = (unsigned)pp.a.nblk;
+  if (blockIdx.x < nA)                                             // workgroup-uniform
+    conv_mfma_f32_body<5, 64, 64, 1, false, false, 4, true, false, true>(pp.a, blockIdx.x, arena);
+  else
+    conv_mfma_f32_body<3, 64, 64, 1, false, false, 4, true, false, true>(pp.b, blockIdx.x - nA, arena);
+}
+
 // OIHW fp32 -> packed [chunk][dy][c][dx][cout]; DGRAD mode packs w'[ci][co][KS-1-dy][KS-1-dx].
 __global__ void pack_weight_f32_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
                                        int cin, int ks, int ck, int dgrad) {
@@ -761,10 +791,21 @@ static int launch_pair_f32(const void* av, const void* bv, hipStream_t stream) {
   return check_launch("conv_mfma_f32_pair_kernel");
 }
 // a cout-split launch: held back by an open pair bracket, else alone with a CU per workgroup
+static int launch_mix53_f32(const void* five, const void* three, hipStream_t stream) {
+  ConvPair pp;
+  pp.a = *static_cast<const ConvParams*>(five);
+  pp.b = *static_cast<const ConvParams*>(three);
+  hipLaunchKernelGGL(conv_mfma_f32_mix53_kernel, dim3((unsigned)pp.a.nblk + (unsigned)pp.b.nblk), dim3(256), 0, stream, pp);
+  return check_launch("conv_mfma_f32_mix53_kernel");
+}
 template <int KS, int CIN, int COUT, bool FUSE, int NW, bool ST = false, bool GATE = false>
 static int launch_or_hold_csplit_f32(const ConvParams& p, hipStream_t stream) {
+  // the plain 64 -> 64 convs can leave as a mix53 grid with their sibling of the other filter size
+  constexpr bool MIXABLE = !FUSE && !GATE && !ST && CIN == 64 && COUT == 64 && NW == 4 && (KS == 5 || KS == 3);
+  constexpr int kind = !MIXABLE ? MIX_NONE : KS == 5 ? MIX_F32_CSPLIT_5 : MIX_F32_CSPLIT_3;
   if (const int held = pair_hold(p, &launch_single_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>,
-                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>, stream))
+                                 &launch_pair_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>, stream, kind,
+                                 (MIXABLE && KS == 5) ? &launch_mix53_f32 : nullptr))
     return held < 0 ? held : CODON_OK;
   return launch_single_f32<KS, CIN, COUT, 1, FUSE, GATE, NW, true, true, ST>(&p, stream);
 }

@@ -15,7 +15,13 @@ struct PairCall {
   hipStream_t stream;                        // the stream the held call was given: pair_end pairs only calls of ITS stream
   int (*single)(const void*, hipStream_t);
   int (*pair)(const void*, const void*, hipStream_t);   // same pointer = same kernel variant
+  // round 6: a conv5x5 64->64 and a conv3x3 64->64 on the SAME input (conv8 | conv9 of the fusion trunk,
+  // /root/reference/CODON_X4/CODON_x4.py:123-124) are two DIFFERENT kernel bodies; held together they leave as one grid of
+  // both kinds of workgroup (mix53).  mix_kind: 0 = none, odd = the 5x5 of a family, the next even number = its 3x3.
+  int mix_kind;
+  int (*mix)(const void* five, const void* three, hipStream_t);     // set by the 5x5 call
 };
+enum { MIX_NONE = 0, MIX_F32_CSPLIT_5 = 1, MIX_F32_CSPLIT_3 = 2, MIX_C8F16_5 = 3, MIX_C8F16_3 = 4, MIX_C8BF16_5 = 5, MIX_C8BF16_3 = 6 };
 struct PairRecorder {
   bool active = false;
   int n = 0;
@@ -28,7 +34,7 @@ PairRecorder* pair_recorder();               // this thread's recorder while a b
 // held ones, so it is refused.
 template <class P>
 inline int pair_hold(const P& p, int (*single)(const void*, hipStream_t), int (*pair)(const void*, const void*, hipStream_t),
-                     hipStream_t stream) {
+                     hipStream_t stream, int mix_kind = MIX_NONE, int (*mix)(const void*, const void*, hipStream_t) = nullptr) {
   static_assert(sizeof(P) <= sizeof(PairCall::blob), "parameter block fits the recorder");
   PairRecorder* r = pair_recorder();
   if (!r) return 0;
@@ -38,6 +44,7 @@ inline int pair_hold(const P& p, int (*single)(const void*, hipStream_t), int (*
   c.nblk = p.nblk; c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
   c.stream = stream;
   c.single = single; c.pair = pair;
+  c.mix_kind = mix_kind; c.mix = mix;
   return 1;
 }
 

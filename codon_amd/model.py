@@ -807,11 +807,18 @@ class _CODONBase(nn.Module):
             if keep:
                 stage = stage if (drop_stage and stage is not None) else new(128)
                 r2, fA = new(128), new(64)
-            with _on_half(1):
-                conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
-            with _on_half(0):
-                conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
-            join()
+            if pairs:
+                # conv8 (5x5) | conv9 (3x3) on the same input: two different kernel bodies as ONE grid (mix53) when the launcher
+                # has that form for this dtype and grid, else two launches in order
+                with pair():
+                    conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
+                    conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
+            else:
+                with _on_half(1):
+                    conv(Slice(f), "conv9", Slice(stage, 64, 64), 3, relu=True)   # :124
+                with _on_half(0):
+                    conv(Slice(f), "conv8", Slice(stage, 0, 64), 5, relu=True)    # :123
+                join()
             conv5_1x1(Slice(stage), "conv10", "confuse_fuse", Slice(r2), Slice(fA), residual=Slice(fuse))  # :126-128
             if keep:
                 save[f"trunk{i}"] = dict(x=f, stage=None if drop_stage else stage, r2=r2)

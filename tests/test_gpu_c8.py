@@ -1268,3 +1268,47 @@ def test_16bit_image_bits_do_not_depend_on_the_batch(mode):
         o1 = m(x[12:13].contiguous(), y[12:13].contiguous())
     assert o1.dtype == dtype and bool(torch.isfinite(o1.float()).all())
     assert torch.equal(o32[12:13], o1) and torch.equal(o5[2:3], o1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 128, 128), (1, 37, 70), (2, 33, 40), (1, 1, 1), (1, 370, 463)])
+def test_mix53_conv5x5_and_conv3x3_as_one_grid(shape, dtype):
+    """Round 6 (VERDICT r5 #1c): conv8 (5x5 64->64) and conv9 (3x3 64->64) of the fusion trunk read the same tensor
+    (/root/reference/CODON_X4/CODON_x4.py:123-124).  Held in one pair bracket they leave as ONE grid of two kinds of workgroup
+    (mix53) where the launcher has that form -- fp32: the small-grid cout-split kernels; 16-bit: up to the pair limit -- with
+    the bits of two separate launches, in either call order; where it has not, as two launches."""
+    from codon_amd import _lib as L, ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    if dtype == torch.float32:
+        x = torch.relu(_rand((B, 64, H, W), 5)).to(dev)
+        new = lambda: torch.full((B, 128, H, W), float("nan"), device=dev)
+    else:
+        x = ops.from_nchw(torch.relu(_rand((B, 64, H, W), 5)).to(dev), dtype)
+        new = lambda: ops.new_act(B, 128, H, W, dtype, dev).fill_(float("nan"))
+    wt = lambda k, seed: ops.packed_weight(_rand((64, 64, k, k), seed, (2.0 / (k * k * 64)) ** 0.5).to(dev), L.PACK_FWD, dtype)
+    w5, w3 = wt(5, 6), wt(3, 7)
+
+    def run(paired, five_first=True):
+        o = new()
+        with ops.conv_pair(dev, paired) as pr:
+            calls = [lambda: ops.conv2d(Slice(x), w5, Slice(o, 0, 64), 5, relu=True),
+                     lambda: ops.conv2d(Slice(x), w3, Slice(o, 64, 64), 3, relu=True)]
+            for c in (calls if five_first else calls[::-1]):
+                c()
+        torch.cuda.synchronize()
+        return o, pr.launches
+
+    ref, _ = run(False)
+    assert not torch.isnan(ref.float()).any()
+    for five_first in (True, False):
+        got, n = run(True, five_first)
+        assert torch.equal(got, ref), (five_first, n)
+        import ctypes as C
+        if dtype == torch.float32:
+            d = L.ConvDesc(B, H, W, 64, 64, 5, 64, 0, 128, 0, 0, 0, L.CONV_RELU, L.F32)
+            expect = 1 if L.load().codon_conv_tiling_f32(C.byref(d), 0, 1) == L.TILING_2X32_COUT_SPLIT else 2
+        else:
+            expect = 1
+        assert n == expect, (n, expect)
