@@ -86,6 +86,7 @@ SIGNATURES = {
     "codon_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _I, _P]),
     "codon_conv1x1_bwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _TP, _P, _P, C.c_size_t, _I, _P]),
     "codon_stem_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "codon_stem_pair_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "codon_head_fwd": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_head_fwd_y16": (C.c_int, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "codon_cac_stats_tiles": (_I, [_I, _I]),

@@ -68,6 +68,8 @@ bool conv_f32x3_supported(const codon_conv_desc*);
 int conv2d_fwd_f32x3(const codon_conv_desc*, const float*, const void*, float*, const float*, hipStream_t);
 int pack_weight_f32x3(const float*, void*, int, int, int, hipStream_t);
 int stem_fwd(int, int, int, const float*, const float*, void*, int, int, int, const void*, int, int, int, hipStream_t);
+int stem_pair_fwd(int, int, int, const float*, const float*, void*, int, int, const float*, const float*, void*, int, int, int,
+                  hipStream_t);
 size_t conv1ch_wgrad_workspace_bytes(int, int, int);
 int conv1ch_wgrad(int, int, int, const void*, int, int, const float*, float*, int, float*, size_t, int, hipStream_t);
 int cac_bwd_tiles(int, int);
@@ -427,6 +429,20 @@ int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
   CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "stem_fwd: dtype %d", dtype);
   return stem_fwd(batch, height, width, x, w_oihw, y, y_ctotal, y_coff, 1, nullptr, 0, 0, dtype,
                   (hipStream_t)stream);
+}
+
+int codon_stem_pair_fwd(int32_t batch, int32_t height, int32_t width, const float* xa, const float* wa_oihw, void* ya,
+                        int32_t ya_ctotal, int32_t ya_coff, const float* xb, const float* wb_oihw, void* yb,
+                        int32_t yb_ctotal, int32_t yb_coff, int32_t dtype, codon_stream_t stream) {
+  CODON_REQUIRE(xa && wa_oihw && ya && xb && wb_oihw && yb, CODON_ERR_BAD_ARG, "stem_pair_fwd: null pointer");
+  CODON_REQUIRE(shape_ok(batch, height, width), CODON_ERR_BAD_ARG, "stem_pair_fwd: bad shape");
+  CODON_REQUIRE(ya_coff >= 0 && ya_coff + 64 <= ya_ctotal && yb_coff >= 0 && yb_coff + 64 <= yb_ctotal, CODON_ERR_BAD_ARG,
+                "stem_pair_fwd: output slice outside buffer");
+  CODON_REQUIRE(ya != yb || ya_coff + 64 <= yb_coff || yb_coff + 64 <= ya_coff, CODON_ERR_BAD_ARG,
+                "stem_pair_fwd: the two output slices overlap");
+  CODON_REQUIRE((dtype == CODON_F32 || dtype == CODON_BF16 || dtype == CODON_F16), CODON_ERR_UNSUPPORTED, "stem_pair_fwd: dtype %d", dtype);
+  return stem_pair_fwd(batch, height, width, xa, wa_oihw, ya, ya_ctotal, ya_coff, xb, wb_oihw, yb, yb_ctotal, yb_coff, dtype,
+                       (hipStream_t)stream);
 }
 
 int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal, int32_t x_coff,

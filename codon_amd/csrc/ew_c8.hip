@@ -48,9 +48,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c8_rsrc(const C8Slice& s, int 
 // instruction covers 64 consecutive pixels of one plane.  Weights live in LDS as [plane][tap][8 ch]: two broadcast
 // ds_read_b128 feed 8 * VEC FMAs.  flags: 1 = ReLU, 2 = spatially flipped taps (dL/dt11 of the head conv).
 template <class E, int VEC>
-__global__ __launch_bounds__(256) void stem_c8_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      C8Slice y, C8Slice mask, int has_mask, int H, int W, int nseg,
-                                                      long nwave, int flags) {
+__device__ __forceinline__ void stem_c8_body(const float* __restrict__ x, const float* __restrict__ w,
+                                             C8Slice y, C8Slice mask, int has_mask, int H, int W, int nseg,
+                                             long nwave, int flags, long blk) {
   __shared__ float wsh[8 * 9 * 8];
   for (int i = threadIdx.x; i < 576; i += 256) {
     const int co = i / 9, t = i % 9;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stem_c8_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const long wid = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wid = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wid >= nwave) return;
   const int seg = (int)(wid % nseg);
   const long t_ = wid / nseg;
@@ -116,6 +116,47 @@ __global__ __launch_bounds__(256) void stem_c8_kernel(const float* __restrict__ 
       c8_st(c8_pack<E>(o[v]), yr, vo[v], (unsigned)cb * HW16);
     }
   }
+}
+
+template <class E, int VEC>
+__global__ __launch_bounds__(256) void stem_c8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      C8Slice y, C8Slice mask, int has_mask, int H, int W, int nseg,
+                                                      long nwave, int flags) {
+  stem_c8_body<E, VEC>(x, w, y, mask, has_mask, H, W, nseg, nwave, flags, (long)blockIdx.x);
+}
+
+// the depth and the guidance stem of a forward as ONE launch (round 6; see stem_pair_kernel in stencil.hip): workgroups
+// [0, nblk) run set a, [nblk, 2 nblk) set b
+template <class E, int VEC>
+__global__ __launch_bounds__(256) void stem_c8_pair_kernel(const float* __restrict__ xa, const float* __restrict__ wa, C8Slice ya,
+                                                           const float* __restrict__ xb, const float* __restrict__ wb, C8Slice yb,
+                                                           int H, int W, int nseg, long nwave, unsigned nblk) {
+  if (blockIdx.x < nblk) stem_c8_body<E, VEC>(xa, wa, ya, ya, 0, H, W, nseg, nwave, 1, (long)blockIdx.x);
+  else stem_c8_body<E, VEC>(xb, wb, yb, yb, 0, H, W, nseg, nwave, 1, (long)(blockIdx.x - nblk));
+}
+
+template <class E>
+static int stem_c8_pair_launch(int B, int H, int W, const float* xa, const float* wa, C8Slice ya, const float* xb,
+                               const float* wb, C8Slice yb, hipStream_t stream) {
+  constexpr int VEC = 2;
+  const int nseg = (W + 64 * VEC - 1) / (64 * VEC);
+  const long nwave = (long)B * H * nseg;
+  const long blocks = (nwave + 3) / 4;
+  CODON_REQUIRE(2 * blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "stem_pair_fwd: grid too large");
+  hipLaunchKernelGGL((stem_c8_pair_kernel<E, VEC>), dim3((unsigned)(2 * blocks)), dim3(256), 0, stream, xa, wa, ya, xb, wb, yb,
+                     H, W, nseg, nwave, (unsigned)blocks);
+  return check_launch("stem_c8_pair_kernel");
+}
+
+int stem_pair_fwd_c8(int B, int H, int W, const float* xa, const float* wa, void* ya, int ya_ctotal, int ya_coff,
+                     const float* xb, const float* wb, void* yb, int yb_ctotal, int yb_coff, int dtype, hipStream_t stream) {
+  CODON_REQUIRE(c8_slice_ok(ya_ctotal, ya_coff, 64) && c8_slice_ok(yb_ctotal, yb_coff, 64), CODON_ERR_BAD_ARG,
+                "stem_pair: 16-bit tensors are channel-blocked: ctotal / coff multiples of 8");
+  const long HW = (long)H * W;
+  CODON_REQUIRE(HW * 2 * 64 < (long)C8_OOB, CODON_ERR_UNSUPPORTED, "stem_pair: image too large for 32-bit buffer offsets");
+  const C8Slice sa = c8_mk(ya, ya_ctotal, ya_coff, HW), sb = c8_mk(yb, yb_ctotal, yb_coff, HW);
+  return dtype == CODON_F16 ? stem_c8_pair_launch<C8F16>(B, H, W, xa, wa, sa, xb, wb, sb, stream)
+                            : stem_c8_pair_launch<C8Bf16>(B, H, W, xa, wa, sa, xb, wb, sb, stream);
 }
 
 template <class E>

@@ -55,14 +55,14 @@ __device__ __forceinline__ void load_row(const T* __restrict__ plane, int gy, in
 // this is dL/dt of the head conv (y = sum_c conv3x3(t_c, w_c)) given dL/dy.
 // mask (optional, 64 channels): out = mask > 0 ? out : 0 (backward through conv11's ReLU).
 template <int VEC, typename T>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   T* __restrict__ y, int H, int W, long y_img,
-                                                   long y_base, long total, int flags,
-                                                   const T* __restrict__ mask, long m_img, long m_base) {
+__device__ __forceinline__ void stem_body(const float* __restrict__ x, const float* __restrict__ w,
+                                          T* __restrict__ y, int H, int W, long y_img,
+                                          long y_base, long total, int flags,
+                                          const T* __restrict__ mask, long m_img, long m_base, long blk) {
   __shared__ float wsh[64 * 9];
   for (int i = threadIdx.x; i < 576; i += 256) wsh[i] = (flags & 2) ? w[(i / 9) * 9 + 8 - (i % 9)] : w[i];
   __syncthreads();
-  const long idx = blockIdx.x * 256L + threadIdx.x;
+  const long idx = blk * 256L + threadIdx.x;
   if (idx >= total) return;
   const int WV = W / VEC;
   const int gxv = (int)(idx % WV);
@@ -109,6 +109,27 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     if constexpr (VEC == 4) st4(yo + co * HW, o);
     else stx(yo + co * HW, o[0]);
   }
+}
+
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   T* __restrict__ y, int H, int W, long y_img,
+                                                   long y_base, long total, int flags,
+                                                   const T* __restrict__ mask, long m_img, long m_base) {
+  stem_body<VEC, T>(x, w, y, H, W, y_img, y_base, total, flags, mask, m_img, m_base, (long)blockIdx.x);
+}
+
+// The depth and the guidance stem of a forward (/root/reference/CODON_X4/CODON_x4.py:68,71) as ONE launch (round 6: at one
+// image per call each was a launch of 10-17 us that covers a fraction of the chip): workgroups [0, nblk) run image set a,
+// [nblk, 2 nblk) set b -- same code per workgroup, same bits.
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void stem_pair_kernel(const float* __restrict__ xa, const float* __restrict__ wa,
+                                                        T* __restrict__ ya, long ya_img, long ya_base,
+                                                        const float* __restrict__ xb, const float* __restrict__ wb,
+                                                        T* __restrict__ yb, long yb_img, long yb_base, int H, int W,
+                                                        long total, unsigned nblk) {
+  if (blockIdx.x < nblk) stem_body<VEC, T>(xa, wa, ya, H, W, ya_img, ya_base, total, 1, nullptr, 0, 0, (long)blockIdx.x);
+  else stem_body<VEC, T>(xb, wb, yb, H, W, yb_img, yb_base, total, 1, nullptr, 0, 0, (long)(blockIdx.x - nblk));
 }
 
 // head: y = sum_c conv3x3(x_c, w_c) + res.  One thread owns VEC consecutive pixels of R consecutive rows (a band): per
@@ -280,6 +301,29 @@ int stem_fwd(int B, int H, int W, const float* x, const float* w, void* y, int y
     return stem_fwd_c8(B, H, W, x, w, y, y_ctotal, y_coff, flags, mask, m_ctotal, m_coff, dtype, stream);
   return stem_launch<float>(B, H, W, x, w, (float*)y, y_ctotal, y_coff, flags, (const float*)mask, m_ctotal, m_coff,
                             stream);
+}
+
+int stem_pair_fwd_c8(int, int, int, const float*, const float*, void*, int, int, const float*, const float*, void*, int, int,
+                     int, hipStream_t);
+
+int stem_pair_fwd(int B, int H, int W, const float* xa, const float* wa, void* ya, int ya_ctotal, int ya_coff,
+                  const float* xb, const float* wb, void* yb, int yb_ctotal, int yb_coff, int dtype, hipStream_t stream) {
+  if (dtype != CODON_F32)
+    return stem_pair_fwd_c8(B, H, W, xa, wa, ya, ya_ctotal, ya_coff, xb, wb, yb, yb_ctotal, yb_coff, dtype, stream);
+  const long HW = (long)H * W;
+  const bool tiny = (long)B * H * W <= 65536;                    // as stem_launch: same form, same bits as the lone launches
+  const bool v4 = !tiny && (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xa) | reinterpret_cast<uintptr_t>(ya) |
+                                             reinterpret_cast<uintptr_t>(xb) | reinterpret_cast<uintptr_t>(yb)) % 16 == 0);
+  const long total = (long)B * H * (v4 ? W / 4 : W);
+  const long blocks = (total + 255) / 256;
+  CODON_REQUIRE(2 * blocks < (1L << 31), CODON_ERR_UNSUPPORTED, "stem_pair_fwd: grid too large");
+  if (v4)
+    hipLaunchKernelGGL((stem_pair_kernel<4, float>), dim3((unsigned)(2 * blocks)), dim3(256), 0, stream, xa, wa, (float*)ya,
+                       ya_ctotal * HW, ya_coff * HW, xb, wb, (float*)yb, yb_ctotal * HW, yb_coff * HW, H, W, total, (unsigned)blocks);
+  else
+    hipLaunchKernelGGL((stem_pair_kernel<1, float>), dim3((unsigned)(2 * blocks)), dim3(256), 0, stream, xa, wa, (float*)ya,
+                       ya_ctotal * HW, ya_coff * HW, xb, wb, (float*)yb, yb_ctotal * HW, yb_coff * HW, H, W, total, (unsigned)blocks);
+  return check_launch("stem_pair_kernel");
 }
 
 template <int VEC, int R, typename T, int DEPTH = 1>

@@ -642,7 +642,6 @@ class _CODONBase(nn.Module):
         # heads: inputs = in2[:, :64] (depth), inputs_c = in2[:, 64:] (colour)     :68-72
         in2 = new(128)
         t64 = new(64)
-        ops.stem(x, w_in, Slice(t64))
         # inference on a small grid (16-bit: at most PAIR_MAX16 tiles; fp32: the small-grid kernels): the depth and the colour
         # conv of every stage as ONE launch
         # (not while bench.py brackets individual conv launches with HIP events: a held launch has no duration of its own)
@@ -651,7 +650,9 @@ class _CODONBase(nn.Module):
         pair = lambda: ops.conv_pair(dev, pairs)
         t64c = new(64) if (keep or pairs) else t64
         if pairs:
-            ops.stem(y, w_in_c, Slice(t64c))
+            ops.stem_pair(x, w_in, Slice(t64), y, w_in_c, Slice(t64c))      # both stems as one launch
+        else:
+            ops.stem(x, w_in, Slice(t64))
         with pair():
             conv(Slice(t64), "conv_input", Slice(in2, 0, 64), 3, relu=True)
             if not pairs:

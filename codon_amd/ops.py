@@ -430,6 +430,18 @@ def stem(x: torch.Tensor, w: torch.Tensor, y: Slice):
                                    _stream(dev)), "stem_fwd")
 
 
+def stem_pair(xa: torch.Tensor, wa: torch.Tensor, ya: Slice, xb: torch.Tensor, wb: torch.Tensor, yb: Slice):
+    """stem(xa, wa, ya) and stem(xb, wb, yb) as one launch (codon_stem_pair_fwd): same bits."""
+    lib = L.load()
+    dev = _dev(xa, wa, ya.buf, xb, wb, yb.buf)
+    B, _, H, W = xa.shape
+    assert xb.shape == xa.shape and ya.c == 64 and yb.c == 64 and ya.buf.dtype == yb.buf.dtype
+    assert all(t.dtype == torch.float32 for t in (xa, wa, xb, wb))
+    with _on(dev):
+        L.check(lib.codon_stem_pair_fwd(B, H, W, _ptr(xa), _ptr(wa), _ptr(ya.buf), ya.ctotal, ya.coff, _ptr(xb), _ptr(wb),
+                                        _ptr(yb.buf), yb.ctotal, yb.coff, _dt(ya.buf), _stream(dev)), "stem_pair_fwd")
+
+
 def head(x: Slice, w: torch.Tensor, residual: torch.Tensor, y: torch.Tensor):
     lib = L.load()
     dev = _dev(x.buf, w, residual, y)

@@ -258,6 +258,12 @@ int codon_conv1x1_bwd_gated(const codon_conv_desc* d, const void* x, const void*
 int codon_stem_fwd(int32_t batch, int32_t height, int32_t width, const float* x,
                    const float* w_oihw, void* y, int32_t y_ctotal, int32_t y_coff, int32_t dtype,
                    codon_stream_t stream);
+/* both stems of a forward -- relu(input(x)) and relu(input_c(y)), CODON_x4.py:68,71 -- as ONE launch (at one image per call,
+ * test.py:116-125, each is a launch of 10-17 us that covers a fraction of the chip): two codon_stem_fwd calls' arguments, the
+ * results bit for bit.  The two output slices must not overlap. */
+int codon_stem_pair_fwd(int32_t batch, int32_t height, int32_t width, const float* xa, const float* wa_oihw, void* ya,
+                        int32_t ya_ctotal, int32_t ya_coff, const float* xb, const float* wb_oihw, void* yb,
+                        int32_t yb_ctotal, int32_t yb_coff, int32_t dtype, codon_stream_t stream);
 int codon_head_fwd(int32_t batch, int32_t height, int32_t width, const void* x, int32_t x_ctotal,
                    int32_t x_coff, const float* w_oihw, const float* residual, float* y,
                    int32_t dtype, codon_stream_t stream);

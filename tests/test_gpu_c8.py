@@ -903,8 +903,9 @@ def test_forward_with_one_launch_gate_and_two_streams_is_bit_identical(mode):
 @pytest.mark.parametrize("dtype", DT)
 def test_conv_pair_is_one_launch_and_bit_identical(dtype):
     """ops.conv_pair (codon_conv_pair_begin / _end): two independent convs of one shape leave as ONE launch with the bits of
-    two launches -- plain, chained 1x1 with statistics, gated + emitting; different shapes / kernels fall back to two
-    launches; a bracket is per thread and cannot nest."""
+    two launches -- plain, chained 1x1 with statistics, gated + emitting; shapes / kernels without a common form fall back to
+    two launches (the 5x5 | 3x3 64->64 couple has one since round 6: test_mix53_conv5x5_and_conv3x3_as_one_grid); a bracket is
+    per thread and cannot nest."""
     from codon_amd import _lib as L, ops
     from codon_amd.ops import Slice
     dev = _dev()
@@ -913,6 +914,7 @@ def test_conv_pair_is_one_launch_and_bit_identical(dtype):
     xa, xb = q(128, 1), q(128, 2)
     wt = lambda co, ci, k, seed: ops.packed_weight(_rand((co, ci, k, k), seed, (2.0 / (k * k * co)) ** 0.5).to(dev), L.PACK_FWD, dtype)
     w5a, w5b, w3a, w3b = wt(64, 64, 5, 3), wt(64, 64, 5, 4), wt(64, 64, 3, 5), wt(64, 64, 3, 6)
+    w3c = wt(64, 128, 3, 9)
 
     def run(paired):
         outs = [ops.new_act(B, 128, H, W, dtype, dev).zero_() for _ in range(4)]
@@ -920,9 +922,9 @@ def test_conv_pair_is_one_launch_and_bit_identical(dtype):
             ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[0], 64, 64), 5, relu=True)
             ops.conv2d(Slice(xb, 64, 64), w5b, Slice(outs[1], 0, 64), 5, relu=True)
         n1 = pr.launches
-        with ops.conv_pair(dev, paired) as pr:             # a 5x5 and a 3x3: not one kernel -> two launches
+        with ops.conv_pair(dev, paired) as pr:             # a 5x5 64->64 and a 3x3 128->64: no common form -> two launches
             ops.conv2d(Slice(xa, 0, 64), w5a, Slice(outs[2], 0, 64), 5)
-            ops.conv2d(Slice(xb, 0, 64), w3b, Slice(outs[2], 64, 64), 3)
+            ops.conv2d(Slice(xb), w3c, Slice(outs[2], 64, 64), 3)
         n2 = pr.launches
         with ops.conv_pair(dev, paired) as pr:
             ops.conv2d(Slice(xa, 64, 64), w3a, Slice(outs[3], 0, 64), 3, relu=True)
@@ -1312,3 +1314,27 @@ def test_mix53_conv5x5_and_conv3x3_as_one_grid(shape, dtype):
         else:
             expect = 1
         assert n == expect, (n, expect)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 128, 128), (2, 19, 45), (1, 1, 1), (1, 370, 463), (3, 300, 256)])
+def test_stem_pair_equals_two_stem_launches(shape, dtype):
+    """codon_stem_pair_fwd (round 6): both stems of a forward (/root/reference/CODON_X4/CODON_x4.py:68,71) as one launch --
+    the bits of two codon_stem_fwd launches, in every form the lone launch takes (one-pixel form for images of a few thousand
+    pixels, four-pixel rows, channel-blocked 16-bit)."""
+    from codon_amd import ops
+    from codon_amd.ops import Slice
+    dev = _dev()
+    B, H, W = shape
+    xa, xb = _rand((B, 1, H, W), 1).to(dev), _rand((B, 1, H, W), 2).to(dev)
+    wa, wb = _rand((64, 1, 3, 3), 3, 0.3).to(dev), _rand((64, 1, 3, 3), 4, 0.3).to(dev)
+    new = (lambda: torch.full((B, 128, H, W), float("nan"), device=dev)) if dtype == torch.float32 else \
+        (lambda: ops.new_act(B, 128, H, W, dtype, dev).fill_(float("nan")))
+    ref, got = new(), new()
+    ops.stem(xa, wa, Slice(ref, 64, 64))
+    ops.stem(xb, wb, Slice(ref, 0, 64))
+    ops.stem_pair(xa, wa, Slice(got, 64, 64), xb, wb, Slice(got, 0, 64))
+    torch.cuda.synchronize()
+    assert not torch.isnan(ref.float()).any() and torch.equal(ref, got)
+    with pytest.raises(RuntimeError, match="overlap"):
+        ops.stem_pair(xa, wa, Slice(got, 0, 64), xb, wb, Slice(got, 0, 64))
