@@ -15,9 +15,11 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 stems = [i for i, r in enumerate(rows) if "stem" in r["Kernel_Name"]]
-# one forward = from a first-stem launch to the next forward's first stem (two stems per forward); take one in the middle
-k = stems[(len(stems) // 4) * 2]
-k2 = stems[(len(stems) // 4) * 2 + 2]
+# one forward = from its first stem launch to the next forward's (round 6: both stems are ONE launch, codon_stem_pair_fwd;
+# before: two stem launches per forward); take one in the middle
+per = 1 if any("pair" in rows[i]["Kernel_Name"] for i in stems) else 2
+k = stems[(len(stems) // (2 * per)) * per]
+k2 = stems[(len(stems) // (2 * per)) * per + per]
 t0 = int(rows[k]["Start_Timestamp"])
 print(f"# one forward: {k2 - k} launches, {(int(rows[k2]['Start_Timestamp']) - t0) / 1e3:.1f} us from its first launch to the next forward's first launch")
 print("# start_us end_us dur_us gap_before_us queue kernel")
