@@ -725,6 +725,10 @@ def main():
     ap.add_argument("--no-script-pattern", action="store_true",
                     help="skip the single-image latencies at the reference script's image sizes (N = 1 default line only)")
     a = ap.parse_args()
+    if os.environ.get("CODON_BENCH_DUMP_S"):
+        # diagnostics: every N seconds every thread's Python stack goes to stderr (where is a slow or hung rank?)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CODON_BENCH_DUMP_S"]), repeat=True, file=sys.stderr)
     if a.scaling == "strong":
         if a.batch % a.gpus != 0:
             raise SystemExit(f"bench.py: --scaling strong needs --batch ({a.batch}) divisible by --gpus ({a.gpus})")

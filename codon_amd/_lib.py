@@ -164,7 +164,7 @@ def load():
         # to any other thread that wants it ~50 times per forward, and the launching thread then queues for it behind that
         # thread's whole time slice (measured: the pipelined test loop of codon_amd.infer ran SLOWER than the serial one,
         # 111 vs 142 images/s, with CDLL).  torch's own blocking calls (synchronize, .item()) still release the lock.
-        lib = C.PyDLL(path)
+        lib = (C.CDLL if os.environ.get("CODON_LIB_CDLL") == "1" else C.PyDLL)(path)     # CODON_LIB_CDLL=1: A/B of the binding mode
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res

@@ -52,6 +52,7 @@ class GradSync:
         self._unused = [p for p in model.parameters() if all(p is not q for q in self.params)]
         self._model = model
         self._armed = 0                            # > 0 only inside direct_backward(): the backward may ADD into the views
+        self._host = None                          # pinned staging copy of the flat buffer (gloo only)
         model.__dict__["_grad_sink"] = weakref.ref(self)      # not a submodule, not pickled (model.__getstate__ drops it)
 
     def direct_backward(self):
@@ -120,6 +121,16 @@ class GradSync:
         if not dist.is_initialized() or self.world_size == 1:
             return None
         self.flat.mul_(1.0 / self.world_size)      # pre-scale: the SUM then is the mean, one pass
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo" and not async_op:
+            # gloo (the one-GPU rehearsals and the fallback when RCCL cannot form a communicator): through a pinned host copy
+            # and gloo's CPU algorithm.  ProcessGroupGloo's own device-tensor path takes SECONDS per call, sporadically, when
+            # the ranks share one card (measured round 6: the 4-rank rehearsal 6 s or 180-235 s; 25 ms per call this way)
+            if self._host is None:
+                self._host = torch.empty(self.flat.shape, dtype=self.flat.dtype, pin_memory=True)
+            self._host.copy_(self.flat, non_blocking=False)
+            dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(self._host, non_blocking=False)
+            return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
 
