@@ -95,8 +95,10 @@ def test_bench_under_the_drivers_torchrun_line():
 def test_bench_four_ranks_strong_scaling_and_diagnostics():
     """4 self-launched ranks sharing the one GPU (gloo rehearsal of the 8-GPU run), --scaling strong: 8 images IN TOTAL,
     2 per rank; rank 0's line carries what a mis-bound multi-GPU run would need to be diagnosed from the record alone."""
+    # (48 x 64: with 64 x 96 images this rehearsal runs in 6 s or, sporadically -- under pytest always --, in ~190 s: four processes
+    # time-slicing one card, every rank waiting in the gradient all-reduce; profiles/r06_rehearsal_4rank_variants.txt, DESIGN 7)
     d = _run(["--gpus", "4", "--backend", "gloo", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--batch", "8",
-              "--height", "64", "--width", "96"])
+              "--height", "48", "--width", "64"])
     assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["rccl_ranks"] == 4
     assert d["config"]["batch_per_gpu"] == 2 and d["config"]["global_batch"] == 8
     assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
