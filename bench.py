@@ -381,7 +381,8 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
     model.train()
     gs = GradSync(model, process_group=data)     # the gradient all-reduce: RCCL (default group) unless the probe failed
     gs.broadcast_parameters(0)
-    opt = torch.optim.Adam(gs.params, lr=1e-4)
+    from codon_amd.dist import FlatAdam
+    opt = FlatAdam(gs, lr=1e-4)                  # torch.optim.Adam's update as ONE launch over the flat gradient buffer
     g = torch.Generator(device=dev); g.manual_seed(99 + rank)
     tgt = torch.rand((B, 1, H, W), generator=g, device=dev)
     crit = L1SSIMLoss(1.0, 1.0)          # BASELINE.json configs[2]: L1 + SSIM
@@ -449,8 +450,9 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "config": {"workload": f"CODON x{scale} forward+backward (L1 + SSIM loss, Adam), batch {B}/GPU at {H}x{W}, "
                                    f"{dtype}" + (" activations/gradients, fp32 accumulate + master weights "
                                                  "(BASELINE.json configs[2] per-GPU shape)" if dtype == "bf16" else "") +
-                                   "; optimizer = torch.optim.Adam over the 44 fp32 tensors: five ATen multi_tensor_apply launches "
-                                   "(~0.1 ms) per step inside the timed region, every other launch is a codon_* HIP kernel",
+                                   "; optimizer = codon_amd.dist.FlatAdam (torch.optim.Adam's update of the 44 fp32 tensors as one "
+                                   "codon_adam_step launch over the flat gradient buffer): every launch of the step is a codon_* "
+                                   "HIP kernel but the fill that zeroes the gradient buffer",
                        "batch_per_gpu": B, "height": H, "width": W, "global_batch": B * world,
                        "parallelism": f"dp{world}: images sharded, one all-reduce of the flat 1 865 506-element gradient per step"},
             "images_per_s": world * B * steps / dt,
@@ -506,7 +508,7 @@ def strong_shards_fwd(model, x, y, dev, full_ms):
 def strong_shards_train(model, x, y, dev, full_ms):
     """The same for the bf16 training step: forward + L1 + SSIM + backward + Adam on 32 / N images (the flat-gradient all-reduce
     is the only thing an N-GPU step adds: `step_minus_allreduce_budget_ms` says how long it may take)."""
-    from codon_amd.dist import GradSync
+    from codon_amd.dist import FlatAdam, GradSync
     from codon_amd.metrics import L1SSIMLoss
     B = x.shape[0]
     ms = {f"b{B}": full_ms}
@@ -518,7 +520,7 @@ def strong_shards_train(model, x, y, dev, full_ms):
         xs, ys = x[:b].contiguous(), y[:b].contiguous()
         g = torch.Generator(device=dev); g.manual_seed(7 + n)
         tgt = torch.rand(xs.shape, generator=g, device=dev)
-        opt = torch.optim.Adam(gs.params, lr=1e-4)
+        opt = FlatAdam(gs, lr=1e-4)
 
         def step():
             gs.zero_grad()

@@ -50,6 +50,13 @@ W1_FLIP, W1_ACCUMULATE, W1_DEFER = 1, 2, 4          # CODON_W1_*
 CAST_MAX = 32                                       # CODON_CAST_MAX
 
 
+ADAM_MAX = 64                                       # CODON_ADAM_MAX
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("param", C.c_void_p * ADAM_MAX), ("count", C.c_int64 * ADAM_MAX)]
+
+
 class CastDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("src", C.c_void_p * CAST_MAX), ("count", C.c_int64 * CAST_MAX),
                 ("dtype", C.c_int32 * CAST_MAX)]
@@ -122,6 +129,7 @@ SIGNATURES = {
     "codon_conv_pair_end": (C.c_int, [_P]),
     "codon_conv_tiling_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int]),
     "codon_cast_multi": (C.c_int, [C.POINTER(CastDesc), _P, _P]),
+    "codon_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "codon_reduce_multi": (C.c_int, [C.POINTER(ReduceItem), _I, _P]),
     "codon_weight_checksum_workspace_bytes": (_S, []),
     "codon_weight_checksum": (C.c_int, [C.POINTER(WsumDesc), _P, _P, _I, _P, _P]),

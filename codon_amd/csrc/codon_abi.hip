@@ -111,6 +111,7 @@ int ssim_l1_bwd(int, int, int, const float*, const float*, const float*, float*,
 
 int reduce_multi(const codon_reduce_item*, int, hipStream_t);
 int cast_multi(const codon_cast_desc*, float*, hipStream_t);
+int adam_step(const codon_adam_desc*, const float*, float*, float*, float, float, float, float, float, int, hipStream_t);
 size_t weight_checksum_workspace_bytes();
 int weight_checksum(const codon_wsum_desc*, void*, unsigned long long*, int, int*, hipStream_t);
 
@@ -602,6 +603,12 @@ int codon_conv_tiling_f32(const codon_conv_desc* d, int chained, int in_pair) {
 int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream) {
   CODON_REQUIRE(desc && dst, CODON_ERR_BAD_ARG, "cast_multi: null pointer");
   return cast_multi(desc, dst, (hipStream_t)stream);
+}
+
+int codon_adam_step(const codon_adam_desc* desc, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, codon_stream_t stream) {
+  CODON_REQUIRE(desc && grad && exp_avg && exp_avg_sq, CODON_ERR_BAD_ARG, "adam_step: null pointer");
+  return adam_step(desc, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 int codon_reduce_multi(const codon_reduce_item* items, int32_t n_items, codon_stream_t stream) {

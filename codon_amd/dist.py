@@ -134,6 +134,42 @@ class GradSync:
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
 
+class FlatAdam:
+    """torch.optim.Adam (amsgrad=False, maximize=False) over a GradSync's parameters as ONE launch per step
+    (codon_adam_step): the gradients are read from the flat all-reduce buffer, the two moments live in flat buffers of the
+    same layout, the fp32 parameters are updated in place (and their Tensor._version bumped: the packed-weight cache and
+    GraphedCODON.stale() see the new values).  Same update as torch.optim.Adam to fp32 rounding (tests/test_gpu_reduce.py)."""
+
+    def __init__(self, gs: GradSync, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        import ctypes as C
+        from . import _lib as L
+        if gs.flat.dtype != torch.float32 or not gs.flat.is_cuda or any(not p.is_contiguous() for p in gs.params):
+            raise NotImplementedError("FlatAdam: fp32 parameters on the GPU")
+        if len(gs.params) > L.ADAM_MAX:
+            raise NotImplementedError(f"FlatAdam: at most {L.ADAM_MAX} tensors")
+        self.gs, self.lr, self.betas, self.eps, self.weight_decay = gs, float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(gs.flat), torch.zeros_like(gs.flat)
+        self.t = 0
+        self._C, self._L = C, L
+
+    def step(self):
+        C, L, gs = self._C, self._L, self.gs
+        gs._install_views()                        # a dropped / foreign .grad is adopted into the flat buffer first
+        d = L.AdamDesc()
+        d.n = len(gs.params)
+        for i, p in enumerate(gs.params):
+            d.param[i], d.count[i] = p.data_ptr(), p.numel()
+        self.t += 1
+        dev = gs.flat.device
+        with torch.cuda.device(dev):
+            L.check(L.load().codon_adam_step(C.byref(d), C.c_void_p(gs.flat.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
+                                             C.c_void_p(self.exp_avg_sq.data_ptr()), self.lr, self.betas[0], self.betas[1],
+                                             self.eps, self.weight_decay, self.t,
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "adam_step")
+        for p in gs.params:                        # written through raw pointers: make the new values visible to version keys
+            torch.autograd.graph.increment_version(p)
+
+
 def shard_batch(n_images: int, rank: int, world: int):
     """Contiguous, balanced image range of `rank` (units = images; no image is split)."""
     base, rem = divmod(n_images, world)

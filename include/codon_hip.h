@@ -494,6 +494,22 @@ typedef struct codon_cast_desc {
 } codon_cast_desc;
 int codon_cast_multi(const codon_cast_desc* desc, float* dst, codon_stream_t stream);
 
+/* ---- one Adam step over all parameter tensors in ONE launch (round 6) -----------------------------------------------------
+ * The reference ships no optimizer; BASELINE.json configs[2] is a training step, and torch.optim.Adam costs five
+ * ATen launches per step.  param[t] (count[t] fp32 elements, updated in place) in the order of the flat gradient buffer `grad`
+ * (codon_amd.dist.GradSync); exp_avg / exp_avg_sq: flat fp32 moment buffers of the same layout (zero before the first step).
+ * torch.optim.Adam's update (amsgrad = False, maximize = False; weight_decay is the L2 form: g += weight_decay * p), `step` = 1,
+ * 2, ...:  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps). */
+#define CODON_ADAM_MAX 64
+typedef struct codon_adam_desc {
+  int32_t n;
+  int32_t reserved;
+  void* param[CODON_ADAM_MAX];
+  int64_t count[CODON_ADAM_MAX];
+} codon_adam_desc;
+int codon_adam_step(const codon_adam_desc* desc, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, codon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,3 +204,46 @@ def test_cac_spatial_weight_gradient_with_a_block_count_that_is_not_a_multiple_o
         torch.cuda.synchronize()
         assert torch.isfinite(dws).all(), defer
         assert rel_rmse(dws.cpu().double(), want) < 2e-6, defer
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_flat_adam_equals_torch_optim_adam(wd):
+    """codon_amd.dist.FlatAdam (codon_adam_step: one launch over all 44 tensors, gradients read from GradSync's flat buffer)
+    against torch.optim.Adam on the same parameters and gradients, five steps: parameters and both moments to fp32 rounding.
+    The packed-weight cache must see the update (Tensor._version is bumped)."""
+    from codon_amd.dist import FlatAdam, GradSync
+    sd = orc.he_state("x4", seed=31)
+    ma, mb = _model(sd), _model(sd)
+    gsa, gsb = GradSync(ma), GradSync(mb)
+    opt_a = FlatAdam(gsa, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    opt_b = torch.optim.Adam(gsb.params, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    v0 = [p._version for p in gsa.params]
+    for step in range(5):
+        grad = (torch.randn(gsa.numel, generator=g) * (0.5 + step)).cuda()
+        gsa.flat.copy_(grad)
+        gsb.flat.copy_(grad)
+        opt_a.step()
+        opt_b.step()
+    torch.cuda.synchronize()
+    assert all(p._version > v for p, v in zip(gsa.params, v0))
+    worst = 0.0
+    for (n, pa), pb in zip(gsa.named, gsb.params):
+        worst = max(worst, rel_rmse(pa.detach().cpu(), pb.detach().cpu()))
+        assert rel_rmse(pa.detach().cpu(), pb.detach().cpu()) <= 1e-6, n
+        # the update itself (what Adam added), not only the parameter it is small against
+        d_a, d_b = (pa.detach() - sd[n].cuda()).cpu(), (pb.detach() - sd[n].cuda()).cpu()
+        assert rel_rmse(d_a, d_b) <= 1e-4, n
+    off = 0
+    for p, pb in zip(gsa.params, gsb.params):
+        st = opt_b.state[pb]
+        k = p.numel()
+        assert rel_rmse(opt_a.exp_avg[off:off + k].cpu(), st["exp_avg"].flatten().cpu()) <= 1e-6
+        assert rel_rmse(opt_a.exp_avg_sq[off:off + k].cpu(), st["exp_avg_sq"].flatten().cpu()) <= 1e-6
+        off += k
+    # a forward after the step runs on re-packed weights (no stale trip), and equals the torch-Adam twin's to fp32 noise
+    x, y = orc.kat_inputs(1, 24, 20)
+    with torch.no_grad():
+        oa, ob = ma.eval()(x.cuda(), y.cuda()), mb.eval()(x.cuda(), y.cuda())
+    ma.check_packed(); mb.check_packed()
+    assert rel_rmse(oa.cpu(), ob.cpu()) <= 1e-5
