@@ -1304,6 +1304,15 @@ def test_mix53_conv5x5_and_conv3x3_as_one_grid(shape, dtype):
 
     ref, _ = run(False)
     assert not torch.isnan(ref.float()).any()
+    # its own oracle anchor: torch's conv2d on the same (16-bit: rounded) operands (nn.Conv2d(64, 64, k, 1, k // 2, bias=False) +
+    # ReLU, /root/reference/CODON_X4/CODON_x4.py:42-43,123-124)
+    xr = x if dtype == torch.float32 else ops.to_nchw(x).float()
+    rnd = (lambda t: t) if dtype == torch.float32 else (lambda t: t.to(dtype).float())
+    r_nchw = ref if dtype == torch.float32 else ops.to_nchw(ref).float()
+    for k, seed, sl in ((5, 6, slice(0, 64)), (3, 7, slice(64, 128))):
+        w = rnd(_rand((64, 64, k, k), seed, (2.0 / (k * k * 64)) ** 0.5).to(dev))
+        want = torch.relu(F.conv2d(xr.double(), w.double(), None, 1, k // 2)).float()
+        assert rel_rmse(r_nchw[:, sl].cpu(), want.cpu()) <= (2e-6 if dtype == torch.float32 else _tol(dtype)), k
     for five_first in (True, False):
         got, n = run(True, five_first)
         assert torch.equal(got, ref), (five_first, n)
@@ -1339,5 +1348,10 @@ def test_stem_pair_equals_two_stem_launches(shape, dtype):
     ops.stem_pair(xa, wa, Slice(got, 64, 64), xb, wb, Slice(got, 0, 64))
     torch.cuda.synchronize()
     assert not torch.isnan(ref.float()).any() and torch.equal(ref, got)
+    # ... and torch's relu(conv2d(1 -> 64, 3x3, pad 1)) on the same operands (CODON_x4.py:24,31,68,71)
+    g_nchw = got if dtype == torch.float32 else ops.to_nchw(got).float()
+    for xi, wi, sl in ((xa, wa, slice(64, 128)), (xb, wb, slice(0, 64))):
+        want = torch.relu(F.conv2d(xi.double(), wi.double(), None, 1, 1)).float()
+        assert rel_rmse(g_nchw[:, sl].cpu(), want.cpu()) <= (2e-6 if dtype == torch.float32 else _tol(dtype))
     with pytest.raises(RuntimeError, match="overlap"):
         ops.stem_pair(xa, wa, Slice(got, 0, 64), xb, wb, Slice(got, 0, 64))
