@@ -478,6 +478,16 @@ def train_leg(model, x, y, dev, dist, rank, world, barrier, steps, warmup, dtype
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
 
 
+def _optional(what, fn):
+    """The side legs of the default line (shard timings, one-image latencies, the script loop, the CPU leg) must never cost the
+    headline: an exception in one of them becomes {"error": ...} in its field and a note on stderr."""
+    try:
+        return fn()
+    except Exception as e:          # noqa: BLE001 -- reported in the line
+        print(f"bench.py: optional leg `{what}` failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return {"error": f"{type(e).__name__}: {e}"[:500]}
+
+
 def _timed_ms(fn, dev, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -905,7 +915,7 @@ def main():
         }
         default_line = world == 1 and (B, H, W, a.scale) == (32, 480, 640, 4) and not bf16 and not split and not rmcr
         if default_line and not a.no_strong_shards:
-            res["strong_shards"] = {"fwd_fp32": strong_shards_fwd(model, x, y, dev, step_s * 1e3)}
+            res["strong_shards"] = {"fwd_fp32": _optional("strong_shards.fwd_fp32", lambda: strong_shards_fwd(model, x, y, dev, step_s * 1e3))}
         if world == 1 and not bf16 and not split and a.mode == "fwd" and not rmcr:
             # OPT-IN mode, reported beside (never instead of) the exact-fp32 headline: same inputs, same K steps
             model.set_conv_precision("f16x3")
@@ -958,14 +968,22 @@ def main():
         tm = (CODONNet16 if a.scale == 16 else CODONNet)().to(dev)
         tm.set_compute_dtype(torch.bfloat16)
         tsteps = 10 if (B, H, W) == (32, 480, 640) else max(3, min(a.steps, 10))     # >= 10 timed iterations
-        leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 2, "bf16", a.scale, a.scaling, ctrl=ctrl, data=data)
+        try:
+            leg = train_leg(tm, x, y, dev, dist, rank, world, barrier, tsteps, 2, "bf16", a.scale, a.scaling, ctrl=ctrl, data=data)
+        except Exception as e:          # noqa: BLE001
+            if world > 1:               # the other ranks are inside the step's collectives: nothing to salvage
+                raise
+            # one rank: the forward line (the headline `value`) is still printed, with the reason the second half is missing
+            print(f"bench.py: the fwd+bwd leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+            res["fwd_bwd"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            leg = None
         shards_train = None
-        if rank == 0 and res is not None and "strong_shards" in res:
+        if leg is not None and rank == 0 and res is not None and "strong_shards" in res:
             torch.cuda.empty_cache()
-            shards_train = strong_shards_train(tm, x, y, dev, leg["ms_per_step"])
+            shards_train = _optional("strong_shards.train_bf16", lambda: strong_shards_train(tm, x, y, dev, leg["ms_per_step"]))
         del tm
         torch.cuda.empty_cache()
-        if rank == 0:
+        if rank == 0 and leg is not None:
             res["fwd_bwd"] = {"it_per_s": leg["value"], "unit": "it/s (whole job: one optimizer step over the global "
                               "batch per iteration)", "images_per_s": leg["images_per_s"], "ms_per_step": leg["ms_per_step"],
                               "steps": leg["steps"], "warmup": leg["warmup"], "dtype": "bf16",
@@ -983,6 +1001,7 @@ def main():
                                   "(fwd_bwd.allreduce_us in an N > 1 line) plus any straggler may add this many ms"}
                 if shards_train is not None:
                     res["strong_shards"]["train_bf16"] = shards_train
+                if shards_train is not None and "ms_per_step" in shards_train:
                     budget["strong_8gpu_ge_6x"] = t1_ / 6.0 - shards_train["ms_per_step"]["b4"]
                     budget["what"] += "; strong scaling (32 images in total): step(b4) + all-reduce must stay below step(b32) / 6"
                 res["fwd_bwd"]["step_minus_allreduce_budget_ms"] = budget
@@ -991,14 +1010,14 @@ def main():
                 r_["train_power_w_p50"], r_["train_sclk_mhz_p50"] = hw_["power_w_p50"], hw_["sclk_mhz_p50"]
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(H, W)
+            res["cpu_baseline"] = _optional("cpu_baseline", lambda: cpu_baseline(H, W))
             if not bf16 and not split and not rmcr:
-                res["config0_on_gpu"] = config0_gpu_latency(dev)
+                res["config0_on_gpu"] = _optional("config0_on_gpu", lambda: config0_gpu_latency(dev))
                 if not a.no_script_pattern:
-                    res["script_pattern_on_gpu"] = script_pattern_latency(dev)
-                    res["script_pattern_on_gpu"]["script_loop"] = script_loop_throughput(dev)
-                    res["script_pattern_on_gpu"]["script_loop_images_per_s"] = \
-                        res["script_pattern_on_gpu"]["script_loop"]["script_loop_images_per_s"]
+                    res["script_pattern_on_gpu"] = _optional("script_pattern_on_gpu", lambda: script_pattern_latency(dev))
+                    loop = _optional("script_loop", lambda: script_loop_throughput(dev))
+                    res["script_pattern_on_gpu"]["script_loop"] = loop
+                    res["script_pattern_on_gpu"]["script_loop_images_per_s"] = loop.get("script_loop_images_per_s")
         if probe is not None and probe.get("any_rank_hung"):
             # a helper thread was still stuck inside an RCCL collective on some rank while the legs were timed --
             # it may have held CUs.  The line says so and the process exits with EXIT_RCCL_HUNG: a driver that looks at the
