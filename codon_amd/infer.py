@@ -43,8 +43,12 @@ def _load_host(a_depth, a_color, a_label, f, tdt):
 
     def conv(p_):
         v = (np.asarray(p_[:h, :w]) / 255).astype(np.float32)
-        t = torch.from_numpy(np.ascontiguousarray(v.astype(ndt) if ndt is not None else v))[None, None]
-        return t if ndt is not None else t.to(tdt)          # bf16 has no numpy type
+        if ndt is not None:
+            return torch.from_numpy(np.ascontiguousarray(v.astype(ndt)))[None, None]
+        # bf16 has no numpy type: round to nearest even on the bit pattern (finite, non-negative inputs)
+        u = np.ascontiguousarray(v).view(np.uint32)
+        b16 = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+        return torch.from_numpy(b16.view(np.int16)).view(torch.bfloat16)[None, None]
 
     lab = torch.from_numpy(io.read_gray(os.path.join(a_label, f)).copy()) if a_label else None
     return conv(px), conv(py), lab, h, w

@@ -223,3 +223,24 @@ def test_infer_cli_end_to_end(tmp_path, capsys):
         assert outs["serial"][0] == outs["pipe"][0] and len(outs["pipe"][0].splitlines()) == 1 + len(sizes) + 2
         assert outs["serial"][1] == outs["pipe"][1]
         assert len({bytes(v) for v in outs["pipe"][1].values()}) == len(sizes)          # five different images came out
+
+
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float16, torch.bfloat16])
+def test_infer_host_conversion_equals_the_reference_steps(tmp_path, tdt):
+    """codon_amd.infer._load_host converts with numpy only (no torch CPU op inside the reader threads); the values must be
+    io.to_input()'s -- float64 divide, float32 (/root/reference/CODON_X4/test.py:116-123) -- followed by the dtype's
+    round-to-nearest-even, bit for bit, with both images cropped to their common size."""
+    from codon_amd import infer, io
+    g = np.random.default_rng(3)
+    for d in ("depth", "color", "label"):
+        os.makedirs(tmp_path / d)
+    dep, col, lab = (g.integers(0, 256, s_).astype(np.uint8) for s_ in ((37, 53), (40, 50), (41, 55)))
+    io.write_gray(str(tmp_path / "depth" / "a.png"), dep)
+    io.write_gray(str(tmp_path / "color" / "a.png"), col)
+    io.write_gray(str(tmp_path / "label" / "a.png"), lab)
+    x, y, l_, h, w = infer._load_host(str(tmp_path / "depth"), str(tmp_path / "color"), str(tmp_path / "label"), "a.png", tdt)
+    assert (h, w) == (37, 50) and x.dtype == tdt and tuple(x.shape) == (1, 1, 37, 50) == tuple(y.shape)
+    assert torch.equal(x, io.to_input(dep)[:, :, :h, :w].to(tdt)) and torch.equal(y, io.to_input(col)[:, :, :h, :w].to(tdt))
+    assert torch.equal(l_, torch.from_numpy(lab))
+    hp = infer._pinned_copy(x) if torch.cuda.is_available() else x
+    assert torch.equal(hp, x)
